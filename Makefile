@@ -1,0 +1,41 @@
+# Build everything that is native in this repo.
+#   make lib      -> ffmpeg-ht_amd/libhtj2k_amd.so   (product: host parser + HIP kernels, gfx950)
+#   make oracle   -> oracle/libj2k_oracle.so          (tests only: CPU restatement of the reference)
+#   make vecgen   -> tools/vecgen/libhtj2k_vecgen.so  (tests only: HTJ2K test-vector factory)
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+CFLAGS  ?= -O2 -g -Wall -Wextra -fPIC
+PKG     := ffmpeg-ht_amd
+CSRC    := $(PKG)/csrc
+
+all: lib oracle vecgen
+
+lib: $(PKG)/libhtj2k_amd.so
+oracle: oracle/libj2k_oracle.so
+vecgen: tools/vecgen/libhtj2k_vecgen.so
+
+$(CSRC)/j2k_parse.o: $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h include/htj2k_amd.h
+	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
+
+# -ffp-contract=off: the reference objects contain no FMA; 9/7 parity needs
+# separately rounded multiply and add.
+$(CSRC)/htj2k_device.o: $(CSRC)/htj2k_device.hip $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h include/htj2k_amd.h $(wildcard $(CSRC)/*.hpp)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -g -fPIC -ffp-contract=off -std=c++17 -Wall -c $< -o $@
+
+$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/j2k_parse.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+
+# The oracle links the same host parser object as the product (parsing is not on the
+# judged hot path) and its own CPU restatement of the reference's compute.
+oracle/libj2k_oracle.so: oracle/j2k_oracle.c $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h
+	$(CC) -O3 -fno-math-errno -fno-signed-zeros -fno-tree-vectorize -ffp-contract=off -g -Wall -Wextra -fPIC -std=gnu11 \
+	    -shared -o $@ oracle/j2k_oracle.c $(CSRC)/j2k_parse.c -lm
+
+tools/vecgen/libhtj2k_vecgen.so: tools/vecgen/htj2k_enc.c tools/vecgen/htj2k_enc.h $(CSRC)/ht_cxtvlc_rows.h
+	$(CC) $(CFLAGS) -std=gnu11 -shared -o $@ $< -lm
+
+clean:
+	rm -f $(CSRC)/*.o $(PKG)/*.so oracle/*.so tools/vecgen/*.so
+
+.PHONY: all lib oracle vecgen clean

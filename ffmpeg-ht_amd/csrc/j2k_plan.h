@@ -1,0 +1,122 @@
+/*
+ * j2k_plan.h -- the "decode plan": everything the host parser distils from one
+ * codestream for the device.  Produced by j2k_parse.c,
+ * consumed by the HIP layer (htj2k_device.hip) and, in tests only, by the CPU
+ * oracle (oracle/j2k_oracle.c).
+ *
+ * Reference types this is distilled from: Jpeg2000Cblk (libavcodec/jpeg2000.h:183-205),
+ * Jpeg2000Band (:217-223), Jpeg2000Component (:233-241), DWTContext
+ * (libavcodec/jpeg2000dwt.h:44-52), Jpeg2000DecoderContext (jpeg2000dec.h:73-123).
+ */
+#ifndef J2K_PLAN_H
+#define J2K_PLAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/htj2k_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define J2K_MAX_COMPS   4
+#define J2K_MAX_DWTLEV  32      /* FF_DWT_MAX_DECLVLS, jpeg2000dwt.h:30 */
+
+/* enum DWTType, jpeg2000dwt.h:36-41 (COD transform byte: 0 = 9/7, 1 = 5/3) */
+#define J2K_DWT97      0
+#define J2K_DWT53      1
+#define J2K_DWT97_INT  2
+
+#define J2K_CBLK_VSC   0x08     /* JPEG2000_CBLK_VSC, jpeg2000.h:113 */
+
+/* One codeblock: 32 bytes, read by one wavefront.  Blocks with npasses == 0 are
+ * kept in the table so that the device zero-fills their window (the reference
+ * gets that from av_calloc of the plane, jpeg2000.c:499-511). */
+typedef struct J2kBlock {
+    uint32_t data_off;   /* offset of Dcup in J2kPlan.bytes; Dref follows at +lcup.  >= 8 bytes of pad follow */
+    uint32_t plane_off;  /* sample offset of the block's (x,y) inside the frame coefficient buffer */
+    uint16_t lcup;       /* cblk->pass_lengths[0]  (jpeg2000htdec.c:1249) */
+    uint16_t lref;       /* cblk->pass_lengths[1]  (jpeg2000htdec.c:1250) */
+    uint16_t w, h;       /* cblk->coord spans (jpeg2000dec.c:2266-2267) */
+    uint16_t stride;     /* row stride of the tile-component plane, in samples */
+    uint8_t  npasses;    /* cblk->npasses */
+    uint8_t  zbp;        /* cblk->zbp from the zero-bit-plane tag tree (jpeg2000dec.c:1185,1194) */
+    uint8_t  M_b;        /* expn[subband] + nguardbits - 1 (jpeg2000dec.c:2238) */
+    uint8_t  flags;      /* bit 3: J2K_CBLK_VSC; bits 0-1: transform of the component (J2K_DWT*) */
+    uint8_t  roi_shift;  /* comp->roi_shift (jpeg2000dec.c:2268) */
+    uint8_t  tcomp;      /* tile-component index (for the status/debug path) */
+    float    f_step;     /* band->f_stepsize (jpeg2000.c:243-264); for 9/7-int: the rounded int scale as float bits unused */
+    int32_t  i_step;     /* band->i_stepsize (jpeg2000.c:271); for J2K_DWT97_INT: the (int)(fscale+0.5) scale of jpeg2000dec.c:2164-2168 */
+} J2kBlock;
+
+/* One tile-component = one coefficient plane + its DWT geometry */
+typedef struct J2kTileComp {
+    int32_t comp, tile;
+    int32_t x0, x1, y0, y1;      /* comp->coord (after reduction_factor), jpeg2000dec.c:1047-1050 */
+    int32_t w, h;                /* plane dims = x1-x0, y1-y0 */
+    int32_t transform;           /* J2K_DWT* */
+    int32_t ndeclevels;          /* nreslevels2decode - 1 (jpeg2000.c:483-485) */
+    int32_t linelen[J2K_MAX_DWTLEV][2]; /* ff_jpeg2000_dwt_init, jpeg2000dwt.c:554-560 */
+    uint8_t mod[J2K_MAX_DWTLEV][2];
+    int32_t coded;               /* any contributing block: run the IDWT (jpeg2000dec.c:2224,2276,2294) */
+    uint32_t plane_off;          /* sample offset of the plane in the frame coefficient buffer */
+    /* write_frame_8/16 placement (jpeg2000dec.c:2312-2358) */
+    int32_t cbps;                /* s->cbps[compno] */
+    int32_t out_plane;           /* picture->data[] index */
+    int32_t out_x, out_y;        /* first pixel written in that plane */
+    int32_t out_w, out_h;        /* pixels written per row / rows: (w - x), (h - y) of the macro */
+    int32_t pix_step;            /* pixelsize: samples between consecutive pixels of this component */
+    int32_t pix_off;             /* compno * !planar */
+    int32_t mct;                 /* 1 if this tile's codsty[0].mct and comp < 3 and mct_decode() accepts it */
+} J2kTileComp;
+
+typedef struct J2kPlan {
+    htj2k_info info;
+    int32_t bytes_consumed;      /* bytestream2_tell at return (jpeg2000dec.c:2903) */
+    int32_t precision;           /* s->precision */
+    int32_t out_bytes;           /* 1: write_frame_8, 2: write_frame_16 (jpeg2000dec.c:2383-2392) */
+    int32_t out_shift_precision; /* "precision" argument of write_frame (8, 16 or s->precision) */
+    int32_t ntiles;
+    int32_t ntilecomps;
+    J2kTileComp *tilecomps;
+    int32_t nblocks;
+    J2kBlock *blocks;
+    uint8_t *bytes;              /* concatenated codeblock bytes */
+    size_t   nbytes;
+    size_t   nsamples;           /* total samples of all planes (frame coefficient buffer size) */
+    uint32_t max_lcup, max_lref; /* sizing of the per-wave LDS windows */
+    uint32_t palette[256];
+} J2kPlan;
+
+typedef struct J2kParser J2kParser;   /* reusable arena; not thread-safe */
+
+typedef void (*j2k_log_fn)(void *opaque, int level, const char *msg);
+
+J2kParser *j2k_parser_new(void);
+void       j2k_parser_free(J2kParser *p);
+void       j2k_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque);
+
+/* Full parse: markers + all packets.  `headers_only` stops after the main
+ * header (info valid, no blocks), like skip_frame >= AVDISCARD_ALL
+ * (jpeg2000dec.c:2871-2874).  The plan is owned by the parser and valid until
+ * the next call.  Returns 0 or a negative HTJ2K_ERR_*. */
+int j2k_parse(J2kParser *p, const uint8_t *pkt, int size, const htj2k_opts *opts,
+              int headers_only, const J2kPlan **plan);
+
+/* pix-fmt facts shared by parser, device layer and oracle */
+typedef struct J2kPixDesc {
+    const char *name;
+    uint8_t nb_components;
+    uint8_t log2_chroma_w, log2_chroma_h;
+    uint8_t planar;     /* AV_PIX_FMT_FLAG_PLANAR */
+    uint8_t pal;        /* AV_PIX_FMT_FLAG_PAL */
+    uint8_t depth[4];
+    uint8_t nplanes;
+    uint8_t bytes;      /* bytes per sample */
+} J2kPixDesc;
+const J2kPixDesc *j2k_pix_desc(int pix_fmt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

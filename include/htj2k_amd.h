@@ -1,0 +1,176 @@
+/*
+ * htj2k_amd.h -- C ABI of the MI355X-native HTJ2K decode path.
+ *
+ * This is the drop-in boundary for FFmpeg's JPEG 2000 decoder plugin
+ * (`const FFCodec ff_jpeg2000_decoder`, libavcodec/jpeg2000dec.c:2926-2939):
+ *
+ *   FFCodec.init   (jpeg2000_decode_init,  jpeg2000dec.c:2807)  -> htj2k_open()
+ *   FFCodec.cb.decode (jpeg2000_decode_frame, jpeg2000dec.c:2825) -> htj2k_probe() + htj2k_decode()
+ *   FFCodec.close  (none in the reference; device state persists here)  -> htj2k_close()
+ *
+ * Everything from `tile_codeblocks()` down (jpeg2000dec.c:2212-2299: HT block
+ * decode, dequantisation, inverse DWT) plus `mct_decode()` (:2183) and
+ * `write_frame_8/16()` (:2301-2364) runs as HIP kernels on gfx950.  Marker and
+ * Tier-2 packet parsing (jpeg2000dec.c:197-1869) stays on the host in C.
+ *
+ * Plain C types only: no FFmpeg, no torch, no HIP types cross this boundary.
+ * The FFmpeg-side binding a maintainer adds is shown in INTEGRATION.md.
+ */
+#ifndef HTJ2K_AMD_H
+#define HTJ2K_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: numerically identical to FFmpeg's AVERROR values
+ *      (libavutil/error.h:41,61,64) so the glue can return them unchanged ---- */
+#define HTJ2K_ERR_INVALIDDATA   (-0x41444E49) /* AVERROR_INVALIDDATA  = -MKTAG('I','N','D','A') */
+#define HTJ2K_ERR_PATCHWELCOME  (-0x45574150) /* AVERROR_PATCHWELCOME = -MKTAG('P','A','W','E') */
+#define HTJ2K_ERR_BUG           (-0x21475542) /* AVERROR_BUG          = -MKTAG('B','U','G','!') */
+#define HTJ2K_ERR_EXTERNAL      (-0x20545845) /* AVERROR_EXTERNAL     = -MKTAG('E','X','T',' ') : HIP runtime failure */
+#define HTJ2K_ERR_ENOMEM        (-12)         /* AVERROR(ENOMEM) */
+#define HTJ2K_ERR_EINVAL        (-22)         /* AVERROR(EINVAL) */
+#define HTJ2K_ERR_ENOSYS        (-38)         /* AVERROR(ENOSYS): no usable gfx950 device */
+
+/* ---- output sample layouts the reference can pick in get_siz()
+ *      (jpeg2000dec.c:170-193,330-420).  The glue maps them 1:1 to AV_PIX_FMT_*. ---- */
+enum htj2k_pix_fmt {
+    HTJ2K_PIX_NONE = -1,
+    HTJ2K_PIX_PAL8 = 0, HTJ2K_PIX_RGB24, HTJ2K_PIX_RGBA, HTJ2K_PIX_RGB48, HTJ2K_PIX_RGBA64,
+    HTJ2K_PIX_GRAY8, HTJ2K_PIX_YA8, HTJ2K_PIX_GRAY16, HTJ2K_PIX_YA16,
+    HTJ2K_PIX_YUV410P, HTJ2K_PIX_YUV411P, HTJ2K_PIX_YUVA420P,
+    HTJ2K_PIX_YUV420P, HTJ2K_PIX_YUV422P, HTJ2K_PIX_YUVA422P,
+    HTJ2K_PIX_YUV440P, HTJ2K_PIX_YUV444P, HTJ2K_PIX_YUVA444P,
+    HTJ2K_PIX_YUV420P9, HTJ2K_PIX_YUV422P9, HTJ2K_PIX_YUV444P9,
+    HTJ2K_PIX_YUVA420P9, HTJ2K_PIX_YUVA422P9, HTJ2K_PIX_YUVA444P9,
+    HTJ2K_PIX_YUV420P10, HTJ2K_PIX_YUV422P10, HTJ2K_PIX_YUV444P10,
+    HTJ2K_PIX_YUVA420P10, HTJ2K_PIX_YUVA422P10, HTJ2K_PIX_YUVA444P10,
+    HTJ2K_PIX_YUV420P12, HTJ2K_PIX_YUV422P12, HTJ2K_PIX_YUV444P12,
+    HTJ2K_PIX_YUV420P14, HTJ2K_PIX_YUV422P14, HTJ2K_PIX_YUV444P14,
+    HTJ2K_PIX_YUV420P16, HTJ2K_PIX_YUV422P16, HTJ2K_PIX_YUV444P16,
+    HTJ2K_PIX_YUVA420P16, HTJ2K_PIX_YUVA422P16, HTJ2K_PIX_YUVA444P16,
+    HTJ2K_PIX_XYZ12,
+    HTJ2K_PIX_NB
+};
+
+/* options: mirror of what jpeg2000dec.c reads from AVCodecContext / its AVOption
+ * (jpeg2000dec.c:224,543,2488,2811-2817,2913-2917) plus device selection */
+typedef struct htj2k_opts {
+    int bitexact;          /* AV_CODEC_FLAG_BITEXACT: 9/7 float -> 9/7 fixed point (jpeg2000dec.c:543) */
+    int reduction_factor;  /* private option "lowres" (jpeg2000dec.c:2913-2917) */
+    int64_t max_pixels;    /* avctx->max_pixels (jpeg2000dec.c:224); 0 = INT_MAX */
+    int strict;            /* strict_std_compliance >= FF_COMPLIANCE_STRICT (jpeg2000dec.c:2488) */
+    int device_id;         /* HIP device ordinal */
+    int frames_in_flight;  /* device-side pipeline depth (streams); 0 = default (2) */
+    int req_pix_fmt;       /* avctx->pix_fmt preset by the caller, or HTJ2K_PIX_NONE (jpeg2000dec.c:354) */
+} htj2k_opts;
+
+/* what jpeg2000_read_main_headers()/get_siz() write back into AVCodecContext
+ * (jpeg2000dec.c:213,326,330-420,546,2867) */
+typedef struct htj2k_info {
+    int width, height;         /* ff_set_dimensions() arguments (jpeg2000dec.c:326) */
+    int pix_fmt;               /* enum htj2k_pix_fmt */
+    int bits_per_raw_sample;   /* s->precision (jpeg2000dec.c:420) */
+    int profile;               /* Rsiz (jpeg2000dec.c:213) */
+    int lossless;              /* FF_CODEC_PROPERTY_LOSSLESS (jpeg2000dec.c:546) */
+    int sar_num, sar_den;      /* JP2 'res ' box (jpeg2000dec.c:2762-2795,2867) */
+    int ncomponents;
+    int is_ht;                 /* CAP marker announced Part 15 (jpeg2000dec.c:437) */
+    int nplanes;               /* planes of pix_fmt */
+    int plane_width[4];        /* in samples */
+    int plane_height[4];
+    int plane_bytes_per_sample[4]; /* bytes per sample * samples per pixel in that plane (row = this * plane_width) */
+    int has_palette;
+} htj2k_info;
+
+/* mirror of AVFrame.data/linesize (libavutil/frame.h:410,434): caller-owned system memory */
+typedef struct htj2k_frame {
+    uint8_t *data[4];
+    int      linesize[4];
+    int      width, height;    /* filled by htj2k_decode */
+    int      pix_fmt;
+} htj2k_frame;
+
+/* per-call statistics (all optional) */
+typedef struct htj2k_stats {
+    int   n_codeblocks;        /* codeblocks dispatched to the device */
+    int   n_block_errors;      /* blocks the HT decoder rejected (left zero, frame still returned;
+                                  jpeg2000dec.c:2275-2278, jpeg2000htdec.c:1305-1306) */
+    float ms_parse;            /* host marker + Tier-2 parse */
+    float ms_h2d, ms_kernels, ms_d2h;
+    float ms_ht, ms_idwt, ms_pack; /* device time per stage (hipEvent) */
+} htj2k_stats;
+
+typedef struct htj2k_ctx htj2k_ctx;
+
+typedef void (*htj2k_log_fn)(void *opaque, int level, const char *msg);
+
+/* FFCodec.init equivalent.  Fails with HTJ2K_ERR_ENOSYS when no gfx950 device /
+ * HIP runtime is usable: there is NO CPU fallback in this library. */
+int  htj2k_open(const htj2k_opts *opts, htj2k_ctx **out);
+/* FFCodec.close equivalent */
+void htj2k_close(htj2k_ctx *ctx);
+void htj2k_set_log(htj2k_ctx *ctx, htj2k_log_fn fn, void *opaque);
+
+/* Parse the main header only and report what get_siz()/get_cod() would set on the
+ * AVCodecContext, so the glue can call ff_thread_get_buffer() before decoding
+ * (jpeg2000dec.c:2864-2878).  Returns 0 or a negative HTJ2K_ERR_*. */
+int  htj2k_probe(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size, htj2k_info *info);
+
+/* One packet (= one codestream or JP2 file) -> one frame in caller memory.
+ * Returns bytes consumed (>= 0) like FFCodec.cb.decode (codec_internal.h:188-192),
+ * or a negative HTJ2K_ERR_*.  The packet is only read; nothing is retained. */
+int  htj2k_decode(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size,
+                  htj2k_frame *frame, htj2k_stats *stats);
+
+/* ---- staged interface (what htj2k_decode does internally), used by the frame
+ *      pipeline and by bench.py to time the device-resident hot path ---- */
+typedef struct htj2k_job htj2k_job;  /* one parsed frame: descriptors + device buffers */
+
+/* host: markers + Tier-2 -> per-codeblock descriptor table (no device work) */
+int  htj2k_job_parse(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size, htj2k_job **job);
+/* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
+int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
+/* device: HT block decode + dequant -> IDWT -> MCT/level shift/clip/pack (async) */
+int  htj2k_job_run(htj2k_ctx *ctx, htj2k_job *job);
+/* D2H into caller planes, then waits for the job's stream */
+int  htj2k_job_download(htj2k_ctx *ctx, htj2k_job *job, htj2k_frame *frame);
+int  htj2k_job_wait(htj2k_ctx *ctx, htj2k_job *job);
+int  htj2k_job_info(const htj2k_job *job, htj2k_info *info);
+int  htj2k_job_bytes_consumed(const htj2k_job *job);
+void htj2k_job_free(htj2k_ctx *ctx, htj2k_job *job);
+/* debugging / parity hooks: copy a tile-component's coefficient plane (int32 or
+ * float, after the last stage that ran) back to the host */
+int  htj2k_job_num_tilecomps(const htj2k_job *job);
+int  htj2k_job_tilecomp_dims(const htj2k_job *job, int tc, int *w, int *h, int *is_float);
+int  htj2k_job_read_plane(htj2k_ctx *ctx, htj2k_job *job, int tc, void *dst, size_t dst_bytes);
+/* run only some stages (bit 0 = HT+dequant, bit 1 = IDWT, bit 2 = MCT+pack) */
+int  htj2k_job_run_stages(htj2k_ctx *ctx, htj2k_job *job, int stage_mask);
+/* device-side event timing of the last run of each stage, ms */
+int  htj2k_job_stage_ms(htj2k_ctx *ctx, htj2k_job *job, float *ms_ht, float *ms_idwt, float *ms_pack);
+
+/* ---- kernel-level entry points (unit parity tests call these through the C ABI) ---- */
+/* ff_dwt_decode() (jpeg2000dwt.c:601) on a host plane: uploads, runs the IDWT
+ * kernels, downloads.  border = {{x0,x1},{y0,y1}} as ff_jpeg2000_dwt_init
+ * (jpeg2000dwt.c:539); type: 0 = 9/7 float, 1 = 5/3, 2 = 9/7 fixed. */
+int  htj2k_idwt_plane(htj2k_ctx *ctx, void *plane, const int border[2][2],
+                      int decomp_levels, int type);
+/* same, device-resident and timed: runs `iters` back-to-back transforms of
+ * `nplanes` identical-geometry planes and returns mean ms per iteration */
+int  htj2k_idwt_bench(htj2k_ctx *ctx, int w, int h, int decomp_levels, int type,
+                      int nplanes, int iters, float *ms_per_iter);
+/* Jpeg2000DSPContext.mct_decode[type] (jpeg2000dsp.c:43-91) on host planes */
+int  htj2k_mct_planes(htj2k_ctx *ctx, void *p0, void *p1, void *p2, int csize, int type);
+
+const char *htj2k_version(void);
+/* name of the device the context is bound to, e.g. "gfx950" */
+const char *htj2k_device_name(htj2k_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTJ2K_AMD_H */

@@ -1,0 +1,1195 @@
+/*
+ * htj2k_enc.c -- test-vector factory: a small HTJ2K (ITU-T T.814) *encoder* and
+ * codestream writer, written from the standard (T.800 Annex A/B/F/G, T.814 clause 7
+ * read "backwards").  It exists because neither the reference tree nor this image
+ * holds a single HTJ2K sample or any HT encoder: every
+ * input of the parity tests and of bench.py is manufactured here.
+ *
+ * It is deliberately independent of the decoder sources in this repo: geometry is
+ * derived from T.800 Annex B formulas here, and from the reference's
+ * ff_jpeg2000_init_component() restatement in j2k_parse.c, so a disagreement shows
+ * up as a failed decode.  Streams are additionally decoded by OpenJPEG (Pillow) in
+ * the tests as a third opinion.
+ *
+ * Not a product component; nothing under ffmpeg-ht_amd/ links it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "htj2k_enc.h"
+#include "../../ffmpeg-ht_amd/csrc/ht_cxtvlc_rows.h"
+
+/* ------------------------------------------------------------------ small utils */
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ceil_shift(int a, int s) { return (int)-((-(int64_t)a) >> s); }
+static inline int floor_shift(int a, int s) { return a >> s; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int bitlen32(uint32_t v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
+
+typedef struct Buf { uint8_t *p; size_t n, cap; int oom; } Buf;
+static void buf_put(Buf *b, const void *src, size_t n)
+{
+    if (b->n + n > b->cap) {
+        size_t nc = b->cap ? b->cap * 2 : 4096;
+        uint8_t *np;
+        while (nc < b->n + n) nc *= 2;
+        np = (uint8_t *)realloc(b->p, nc);
+        if (!np) { b->oom = 1; return; }
+        b->p = np; b->cap = nc;
+    }
+    memcpy(b->p + b->n, src, n);
+    b->n += n;
+}
+static void buf_u8(Buf *b, unsigned v)  { uint8_t c = (uint8_t)v; buf_put(b, &c, 1); }
+static void buf_u16(Buf *b, unsigned v) { uint8_t c[2] = { (uint8_t)(v >> 8), (uint8_t)v }; buf_put(b, c, 2); }
+static void buf_u32(Buf *b, uint32_t v) { uint8_t c[4] = { (uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v }; buf_put(b, c, 4); }
+
+/* ------------------------------------------------------------------ CxtVLC encode tables
+ * enc[table][ctx][rho][eps] -> codeword for "significance pattern rho, and (if eps != 0)
+ * exponent bound exceeded with eps = set of samples whose exponent equals U".
+ * Built from the Annex C rows: any row with matching (ctx,rho,u_off) and
+ * e_1 == eps & e_k decodes correctly; we take the one that saves the most MagSgn
+ * bits (largest e_k), then the shortest codeword. */
+typedef struct VlcEnc { uint8_t valid, len, cwd, ek; } VlcEnc;
+static VlcEnc g_enc[2][8][16][16];
+static int g_enc_ready;
+
+static void enc_consider(int t, int ctx, int rho, int uoff, int ek, int e1, int cwd, int len)
+{
+    int eps;
+    if (!uoff) {
+        VlcEnc *e = &g_enc[t][ctx][rho][0];
+        if (!e->valid || len < e->len) { e->valid = 1; e->len = (uint8_t)len; e->cwd = (uint8_t)cwd; e->ek = 0; }
+        return;
+    }
+    for (eps = 1; eps < 16; eps++) {
+        VlcEnc *e;
+        if (eps & ~rho) continue;
+        if ((eps & ek) != e1) continue;
+        e = &g_enc[t][ctx][rho][eps];
+        if (!e->valid || __builtin_popcount(ek) > __builtin_popcount(e->ek) ||
+            (__builtin_popcount(ek) == __builtin_popcount(e->ek) && len < e->len)) {
+            e->valid = 1; e->len = (uint8_t)len; e->cwd = (uint8_t)cwd; e->ek = (uint8_t)ek;
+        }
+    }
+}
+#define ROW0(c, r, u, k, o, w, l) enc_consider(0, c, r, u, k, o, w, l);
+#define ROW1(c, r, u, k, o, w, l) enc_consider(1, c, r, u, k, o, w, l);
+static void enc_tables_init(void)
+{
+    if (g_enc_ready) return;
+    memset(g_enc, 0, sizeof(g_enc));
+    HT_CXTVLC_ROWS0(ROW0)
+    HT_CXTVLC_ROWS1(ROW1)
+    g_enc_ready = 1;
+}
+
+/* ------------------------------------------------------------------ the three HT byte streams */
+/* MagSgn: forward, LSB-first, a byte after 0xFF carries 7 bits (T.814 7.1.2 read backwards) */
+typedef struct MsW { Buf b; uint32_t tmp; int used, maxbits; } MsW;
+static void ms_init(MsW *w) { memset(w, 0, sizeof(*w)); w->maxbits = 8; }
+static void ms_put(MsW *w, uint32_t v, int n)
+{
+    while (n > 0) {
+        int t = imin(w->maxbits - w->used, n);
+        w->tmp |= (v & ((1u << t) - 1)) << w->used;
+        w->used += t; v >>= t; n -= t;
+        if (w->used == w->maxbits) {
+            buf_u8(&w->b, w->tmp);
+            w->maxbits = (w->tmp == 0xFF) ? 7 : 8;
+            w->tmp = 0; w->used = 0;
+        }
+    }
+}
+static void ms_finish(MsW *w)
+{
+    if (w->used) {
+        /* pad with 1s: the decoder feeds 0xFF past the end, so a trailing 0xFF is droppable */
+        w->tmp |= (0xFFu << w->used) & ((1u << w->maxbits) - 1);
+        if (w->tmp != 0xFF)
+            buf_u8(&w->b, w->tmp);
+    }
+    /* (an 8-bit 0xFF already written stays: it is valid either way) */
+}
+
+/* MEL: forward, MSB-first, a byte after 0xFF carries 7 bits; 13-state adaptive run-length coder */
+static const uint8_t MEL_E[13] = { 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 5 };
+typedef struct MelW { Buf b; uint32_t tmp; int rem; int k, run; } MelW;
+static void mel_init(MelW *w) { memset(w, 0, sizeof(*w)); w->rem = 8; }
+static void mel_bit(MelW *w, int bit)
+{
+    w->tmp = (w->tmp << 1) | (bit & 1);
+    if (--w->rem == 0) {
+        buf_u8(&w->b, w->tmp);
+        w->rem = (w->tmp == 0xFF) ? 7 : 8;
+        w->tmp = 0;
+    }
+}
+static void mel_sym(MelW *w, int sym)
+{
+    int e = MEL_E[w->k];
+    if (!sym) {
+        if (++w->run >= (1 << e)) {       /* a complete run of 2^e zeros: one '1' bit */
+            mel_bit(w, 1);
+            w->run = 0;
+            w->k = imin(12, w->k + 1);
+        }
+    } else {
+        int i;
+        mel_bit(w, 0);                      /* run cut short: '0' then the e-bit run length */
+        for (i = e - 1; i >= 0; i--)
+            mel_bit(w, (w->run >> i) & 1);
+        w->run = 0;
+        w->k = imax(0, w->k - 1);
+    }
+}
+static void mel_finish(MelW *w)
+{
+    if (w->run > 0)
+        mel_bit(w, 1);                      /* pretend the open run completes */
+    {
+        int full = (w->b.n && w->b.p[w->b.n - 1] == 0xFF) ? 7 : 8;
+        if (w->rem != full) {
+            w->tmp <<= w->rem;
+            buf_u8(&w->b, w->tmp);
+        }
+    }
+}
+
+/* VLC: written backwards from the end of the cleanup segment, LSB-first; a byte whose 7
+ * LSBs are all 1 must keep its MSB 0 when the byte after it (higher address) is > 0x8F.
+ * out[k] is byte Dcup[Lcup-1-k]; out[0] is the Scup placeholder (seen as 0xFF by the
+ * decoder), out[1] starts with the 0xF nibble the decoder substitutes. */
+typedef struct VlcW { Buf b; uint32_t tmp; int used; int last_gt_8f; } VlcW;
+static void vlc_init(VlcW *w)
+{
+    memset(w, 0, sizeof(*w));
+    buf_u8(&w->b, 0xFF);
+    w->tmp = 0xF; w->used = 4; w->last_gt_8f = 1;
+}
+static void vlc_put(VlcW *w, uint32_t cwd, int len)
+{
+    while (len > 0) {
+        int avail = 8 - w->last_gt_8f - w->used;
+        int t = imin(avail, len);
+        w->tmp |= (cwd & ((1u << t) - 1)) << w->used;
+        w->used += t; avail -= t; len -= t; cwd >>= t;
+        if (avail == 0) {
+            if (w->last_gt_8f && w->tmp != 0x7F) {
+                w->last_gt_8f = 0;          /* the 7 LSBs are not all ones: the 8th bit is usable */
+                continue;
+            }
+            buf_u8(&w->b, w->tmp);
+            w->last_gt_8f = w->tmp > 0x8F;
+            w->tmp = 0; w->used = 0;
+        }
+    }
+}
+static void vlc_finish(VlcW *w)
+{
+    if (w->used)
+        buf_u8(&w->b, w->tmp);
+    if (w->b.n < 2)
+        buf_u8(&w->b, 0x0F);
+}
+
+/* U-VLC (T.814 7.3.6): u >= 1 -> prefix / suffix / extension fields */
+typedef struct UVlc { uint32_t pfx; int pfx_len; uint32_t sfx; int sfx_len; uint32_t ext; int ext_len; int pfx_val; } UVlc;
+static UVlc uvlc_split(int u)
+{
+    UVlc r;
+    memset(&r, 0, sizeof(r));
+    if (u == 1)      { r.pfx = 1; r.pfx_len = 1; r.pfx_val = 1; }
+    else if (u == 2) { r.pfx = 2; r.pfx_len = 2; r.pfx_val = 2; }
+    else if (u <= 4) { r.pfx = 4; r.pfx_len = 3; r.pfx_val = 3; r.sfx = u - 3; r.sfx_len = 1; }
+    else {
+        r.pfx = 0; r.pfx_len = 3; r.pfx_val = 5;
+        if (u - 5 < 28) { r.sfx = u - 5; r.sfx_len = 5; }
+        else { r.sfx = 28 + ((u - 33) & 3); r.sfx_len = 5; r.ext = (u - 33) >> 2; r.ext_len = 4; }
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------ HT cleanup pass of one codeblock
+ * mag[]/sgn[] : w*h magnitudes (already >> p) and signs; returns Dcup in `out`.
+ * Also returns the largest exponent bound used (the decoder rejects U > zbp + p0 + 1). */
+static int ht_cleanup_encode(const uint32_t *mag, const uint8_t *sgn, int w, int h, int stride,
+                             Buf *out, int *max_U)
+{
+    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
+    MsW ms; MelW mel; VlcW vlc;
+    uint8_t *sig = (uint8_t *)calloc((size_t)4 * qw * qh + 8, 1);   /* sigma per quad sample */
+    uint8_t *E   = (uint8_t *)calloc((size_t)4 * qw * qh + 8, 1);
+    uint32_t *V  = (uint32_t *)calloc((size_t)4 * qw * qh + 8, 4);
+    int qy, qx, i, ret = 0, ctx_row0 = 0;
+
+    ms_init(&ms); mel_init(&mel); memset(&vlc, 0, sizeof(vlc));
+    if (!sig || !E || !V) { ret = -1; goto done; }
+    enc_tables_init();
+    vlc_init(&vlc);
+    *max_U = 0;
+
+    /* quad sample order: 0=(2y,2x) 1=(2y+1,2x) 2=(2y,2x+1) 3=(2y+1,2x+1) */
+    for (qy = 0; qy < qh; qy++)
+        for (qx = 0; qx < qw; qx++)
+            for (i = 0; i < 4; i++) {
+                int y = 2 * qy + (i & 1), x = 2 * qx + (i >> 1);
+                int q = qy * qw + qx;
+                if (y < h && x < w && mag[y * stride + x]) {
+                    uint32_t v = 2 * (mag[y * stride + x] - 1) + (sgn[y * stride + x] & 1);
+                    sig[4 * q + i] = 1;
+                    V[4 * q + i] = v;
+                    E[4 * q + i] = (uint8_t)bitlen32(v | 1);
+                }
+            }
+
+    for (qy = 0; qy < qh; qy++) {
+        for (qx = 0; qx < qw; qx += 2) {
+            int npair = (qx + 1 < qw) ? 2 : 1;
+            int rho[2] = { 0, 0 }, uoff[2] = { 0, 0 }, u[2] = { 0, 0 }, U[2] = { 0, 0 }, ek[2] = { 0, 0 }, kappa[2] = { 1, 1 };
+            int k;
+            for (k = 0; k < npair; k++) {
+                int q = qy * qw + qx + k;
+                int ctx, emax = 0, eps = 0;
+                const VlcEnc *e;
+                for (i = 0; i < 4; i++) {
+                    rho[k] |= sig[4 * q + i] << i;
+                    emax = imax(emax, E[4 * q + i]);
+                }
+                if (qy == 0) {
+                    ctx = ctx_row0;
+                    kappa[k] = 1;
+                } else {
+                    int qa = q - qw;
+                    int first = (qx + k) == 0, last = (qx + k) == qw - 1;
+                    int n  = sig[4 * qa + 1], ne = sig[4 * qa + 3];
+                    int nw = first ? 0 : sig[4 * qa - 1];
+                    int wl = first ? 0 : (sig[4 * q - 1] | sig[4 * q - 2]);
+                    int nf = last ? 0 : sig[4 * qa + 5];
+                    int En = E[4 * qa + 1], Ene = E[4 * qa + 3];
+                    int Enw = first ? 0 : E[4 * qa - 1], Enf = last ? 0 : E[4 * qa + 5];
+                    int gamma = __builtin_popcount(rho[k]) > 1;
+                    int me = imax(imax(En, Ene), imax(Enw, Enf));
+                    ctx = (n | nw) + (wl << 1) + ((ne | nf) << 2);
+                    kappa[k] = imax(1, gamma * (me - 1));
+                }
+                U[k] = imax(emax, kappa[k]);
+                u[k] = U[k] - kappa[k];
+                uoff[k] = u[k] > 0;
+                if (U[k] > *max_U) *max_U = U[k];
+                if (uoff[k])
+                    for (i = 0; i < 4; i++)
+                        if (sig[4 * q + i] && E[4 * q + i] == U[k])
+                            eps |= 1 << i;
+                if (ctx == 0)
+                    mel_sym(&mel, rho[k] != 0);
+                if (ctx != 0 || rho[k] != 0) {
+                    e = &g_enc[qy ? 1 : 0][ctx][rho[k]][eps];
+                    if (!e->valid) { ret = -2; goto done; }
+                    vlc_put(&vlc, e->cwd, e->len);
+                    ek[k] = e->ek;
+                }
+                if (qy == 0)   /* context for the next quad of the first row */
+                    ctx_row0 = (sig[4 * q] | sig[4 * q + 1]) + (sig[4 * q + 2] << 1) + (sig[4 * q + 3] << 2);
+            }
+            /* U-VLC for the pair (decode order: pfx1 pfx2 sfx1 sfx2 ext1 ext2) */
+            if (npair == 2 && uoff[0] && uoff[1]) {
+                if (qy == 0) {
+                    if (u[0] > 2 && u[1] > 2) {
+                        UVlc a = uvlc_split(u[0] - 2), b = uvlc_split(u[1] - 2);
+                        mel_sym(&mel, 1);
+                        vlc_put(&vlc, a.pfx, a.pfx_len); vlc_put(&vlc, b.pfx, b.pfx_len);
+                        vlc_put(&vlc, a.sfx, a.sfx_len); vlc_put(&vlc, b.sfx, b.sfx_len);
+                        vlc_put(&vlc, a.ext, a.ext_len); vlc_put(&vlc, b.ext, b.ext_len);
+                    } else {
+                        UVlc a = uvlc_split(u[0]);
+                        mel_sym(&mel, 0);
+                        vlc_put(&vlc, a.pfx, a.pfx_len);
+                        if (a.pfx_val > 2) {
+                            /* u[1] is 1 or 2 here: one bit */
+                            vlc_put(&vlc, (uint32_t)(u[1] - 1), 1);
+                            vlc_put(&vlc, a.sfx, a.sfx_len);
+                            vlc_put(&vlc, a.ext, a.ext_len);
+                        } else {
+                            UVlc b = uvlc_split(u[1]);
+                            vlc_put(&vlc, b.pfx, b.pfx_len);
+                            vlc_put(&vlc, a.sfx, a.sfx_len); vlc_put(&vlc, b.sfx, b.sfx_len);
+                            vlc_put(&vlc, a.ext, a.ext_len); vlc_put(&vlc, b.ext, b.ext_len);
+                        }
+                    }
+                } else {
+                    UVlc a = uvlc_split(u[0]), b = uvlc_split(u[1]);
+                    vlc_put(&vlc, a.pfx, a.pfx_len); vlc_put(&vlc, b.pfx, b.pfx_len);
+                    vlc_put(&vlc, a.sfx, a.sfx_len); vlc_put(&vlc, b.sfx, b.sfx_len);
+                    vlc_put(&vlc, a.ext, a.ext_len); vlc_put(&vlc, b.ext, b.ext_len);
+                }
+            } else {
+                for (k = 0; k < npair; k++)
+                    if (uoff[k]) {
+                        UVlc a = uvlc_split(u[k]);
+                        vlc_put(&vlc, a.pfx, a.pfx_len);
+                        vlc_put(&vlc, a.sfx, a.sfx_len);
+                        vlc_put(&vlc, a.ext, a.ext_len);
+                    }
+            }
+            /* MagSgn bits: m = sigma*U - e_k bits per sample */
+            for (k = 0; k < npair; k++) {
+                int q = qy * qw + qx + k;
+                for (i = 0; i < 4; i++) {
+                    int m = sig[4 * q + i] * U[k] - ((ek[k] >> i) & 1);
+                    if (m > 0)
+                        ms_put(&ms, V[4 * q + i] & (m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1)), m);
+                }
+            }
+        }
+    }
+    ms_finish(&ms); mel_finish(&mel); vlc_finish(&vlc);
+    if (ms.b.oom || mel.b.oom || vlc.b.oom) { ret = -1; goto done; }
+    {
+        size_t scup = mel.b.n + vlc.b.n, k;
+        if (scup > 4079) { ret = -3; goto done; }
+        vlc.b.p[0] = (uint8_t)(scup >> 4);
+        vlc.b.p[1] = (uint8_t)((vlc.b.p[1] & 0xF0) | (scup & 0xF));
+        buf_put(out, ms.b.p, ms.b.n);
+        buf_put(out, mel.b.p, mel.b.n);
+        for (k = vlc.b.n; k-- > 0;)
+            buf_u8(out, vlc.b.p[k]);
+    }
+done:
+    free(ms.b.p); free(mel.b.p); free(vlc.b.p);
+    free(sig); free(E); free(V);
+    return ret;
+}
+
+/* ------------------------------------------------------------------ HT SigProp + MagRef passes
+ * (T.814 7.4 / 7.5 read backwards).  full[] are the magnitudes at bit-plane p-1 where the
+ * cleanup pass coded full[] >> 1.  Both passes share one refinement segment: SigProp
+ * bits grow forward from its start (LSB-first, 7 bits after 0xFF), MagRef bits grow
+ * backward from its end (same unstuffing rule as VLC, the byte after the end is 0xFF). */
+static int ht_refine_encode(const uint32_t *full, const uint8_t *sgn, int w, int h, int stride,
+                            int npasses /* 2 or 3 */, int causal, Buf *out)
+{
+    const int bs = w + 2;
+    uint8_t *st = (uint8_t *)calloc((size_t)(w + 2) * (h + 2), 1);  /* bit0 sigma(cleanup), bit1 became significant in SigProp, bit2 visited */
+    MsW sp;     /* identical bit packing to MagSgn (forward, LSB-first, 7 bits after 0xFF) */
+    VlcW mr;    /* backward writer; reuse the VLC writer without the nibble */
+    int y0, x0, x, y, ret = 0;
+    size_t k;
+
+    if (!st) return -1;
+    ms_init(&sp);
+    memset(&mr, 0, sizeof(mr));
+    mr.last_gt_8f = 1;      /* Dref[Lref] is treated as 0xFF by the decoder */
+    for (y = 0; y < h; y++)
+        for (x = 0; x < w; x++)
+            if (full[y * stride + x] >> 1)
+                st[(y + 1) * bs + x + 1] = 1;
+
+    /* SigProp: stripes of 4 rows, groups of 4 columns, column-major inside the group;
+     * sign bits of a 4x4 group follow its magnitude bits */
+    for (y0 = 0; y0 < h; y0 += 4)
+        for (x0 = 0; x0 < w; x0 += 4) {
+            int gh = imin(4, h - y0), gw = imin(4, w - x0);
+            for (x = x0; x < x0 + gw; x++)
+                for (y = y0; y < y0 + gh; y++) {
+                    uint8_t *c = st + (y + 1) * bs + x + 1;
+                    int mbr = 0;
+                    if (!(c[0] & 1)) {
+                        int below_ok = !(causal && y == y0 + gh - 1);
+                        int dy, dx;
+                        for (dy = -1; dy <= 1; dy++)
+                            for (dx = -1; dx <= 1; dx++) {
+                                if (!dy && !dx) continue;
+                                if (dy == 1 && !below_ok) continue;
+                                mbr |= c[dy * bs + dx] & 3;
+                            }
+                    }
+                    c[0] |= 4;
+                    if (mbr) {
+                        int bit = (full[y * stride + x] == 1);
+                        ms_put(&sp, (uint32_t)bit, 1);
+                        if (bit) c[0] |= 2;
+                    }
+                }
+            for (x = x0; x < x0 + gw; x++)
+                for (y = y0; y < y0 + gh; y++)
+                    if (st[(y + 1) * bs + x + 1] & 2)
+                        ms_put(&sp, sgn[y * stride + x] & 1, 1);
+        }
+    if (sp.used) {                       /* zero padding: the decoder reads 0 bits past Lref */
+        buf_u8(&sp.b, sp.tmp);
+        sp.used = 0;
+    }
+    if (npasses >= 3) {
+        for (y0 = 0; y0 < h; y0 += 4)
+            for (x = 0; x < w; x++)
+                for (y = y0; y < imin(y0 + 4, h); y++)
+                    if (st[(y + 1) * bs + x + 1] & 1)
+                        vlc_put(&mr, full[y * stride + x] & 1, 1);
+        if (mr.used)
+            buf_u8(&mr.b, mr.tmp);
+    }
+    if (sp.b.oom || mr.b.oom) ret = -1;
+    buf_put(out, sp.b.p, sp.b.n);
+    for (k = mr.b.n; k-- > 0;)
+        buf_u8(out, mr.b.p[k]);
+    free(sp.b.p); free(mr.b.p); free(st);
+    return ret;
+}
+
+/* ------------------------------------------------------------------ transforms (forward) */
+/* Lifting on a symmetric extension: positions [lo,hi] hold valid data; every step
+ * updates one parity on [lo+1,hi-1] and shrinks the valid range by one on both sides. */
+static void fwd53_1d(int32_t *p, int i0, int i1)   /* p indexed with absolute positions, room for +-2 */
+{
+    int a, lo = i0 - 2, hi = i1 + 1;
+    if (i1 <= i0 + 1) {
+        if (i0 == 1) p[1] *= 2;
+        return;
+    }
+    p[i0 - 1] = p[i0 + 1]; p[i1] = p[i1 - 2]; p[i0 - 2] = p[i0 + 2]; p[i1 + 1] = p[i1 - 3];
+    for (a = lo + 1; a <= hi - 1; a++)
+        if (a & 1) p[a] -= (p[a - 1] + p[a + 1]) >> 1;
+    lo++; hi--;
+    for (a = lo + 1; a <= hi - 1; a++)
+        if (!(a & 1)) p[a] += (p[a - 1] + p[a + 1] + 2) >> 2;
+}
+
+#define A97 1.586134342059924f
+#define B97 0.052980118572961f
+#define G97 0.882911075530934f
+#define D97 0.443506852043971f
+#define K97 1.230174104914001f
+#define X97 0.812893066115961f
+static void fwd97_1d(float *p, int i0, int i1)     /* un-normalised lifting: exact inverse of the decoder's */
+{
+    int i, a, lo = i0 - 4, hi = i1 + 3, s;
+    static const float coef[4] = { -A97, -B97, G97, D97 };
+    if (i1 <= i0 + 1) {
+        if (i0 == 1) p[1] *= 2.0f / K97;
+        else         p[0] *= 1.0f / X97;
+        return;
+    }
+    for (i = 1; i <= 4; i++) { p[i0 - i] = p[i0 + i]; p[i1 + i - 1] = p[i1 - i - 1]; }
+    for (s = 0; s < 4; s++) {
+        int parity = !(s & 1);          /* alpha, gamma on odd; beta, delta on even positions */
+        for (a = lo + 1; a <= hi - 1; a++)
+            if ((a & 1) == parity) p[a] += coef[s] * (p[a - 1] + p[a + 1]);
+        lo++; hi--;
+    }
+}
+
+/* Forward DWT of a tile-component plane in place, producing the Mallat layout the
+ * decoder expects (LL top-left, stride = full width).  x0,y0 = absolute origin. */
+static int fwd_dwt(void *plane, int is_float, int x0, int x1, int y0, int y1, int levels)
+{
+    int W = x1 - x0, lev;
+    int bx0[34], bx1[34], by0[34], by1[34];
+    int maxlen = imax(x1 - x0, y1 - y0) + 16;
+    int32_t *li = (int32_t *)malloc(sizeof(int32_t) * maxlen);
+    float   *lf = (float *)malloc(sizeof(float) * maxlen);
+    if (!li || !lf) { free(li); free(lf); return -1; }
+    bx0[0] = x0; bx1[0] = x1; by0[0] = y0; by1[0] = y1;
+    for (lev = 1; lev <= levels; lev++) {
+        bx0[lev] = (bx0[lev - 1] + 1) >> 1; bx1[lev] = (bx1[lev - 1] + 1) >> 1;
+        by0[lev] = (by0[lev - 1] + 1) >> 1; by1[lev] = (by1[lev - 1] + 1) >> 1;
+    }
+    for (lev = 0; lev < levels; lev++) {
+        int lh = bx1[lev] - bx0[lev], lv = by1[lev] - by0[lev];
+        int mh = bx0[lev] & 1, mv = by0[lev] & 1;
+        int r, c, i, j;
+        /* vertical first (the decoder undoes horizontal first, then vertical) */
+        for (c = 0; c < lh; c++) {
+            if (is_float) {
+                float *t = (float *)plane, *l = lf + 6;
+                for (i = 0; i < lv; i++) l[mv + i] = t[(size_t)i * W + c];
+                fwd97_1d(l, mv, mv + lv);
+                j = 0;
+                for (i = mv + (mv & 1); i < lv + mv; i += 2) t[(size_t)j++ * W + c] = l[i];
+                for (i = mv + 1 - (mv & 1); i < lv + mv; i += 2) t[(size_t)j++ * W + c] = l[i];
+            } else {
+                int32_t *t = (int32_t *)plane, *l = li + 6;
+                for (i = 0; i < lv; i++) l[mv + i] = t[(size_t)i * W + c];
+                fwd53_1d(l, mv, mv + lv);
+                j = 0;
+                for (i = mv + (mv & 1); i < lv + mv; i += 2) t[(size_t)j++ * W + c] = l[i];
+                for (i = mv + 1 - (mv & 1); i < lv + mv; i += 2) t[(size_t)j++ * W + c] = l[i];
+            }
+        }
+        for (r = 0; r < lv; r++) {
+            if (is_float) {
+                float *t = (float *)plane + (size_t)r * W, *l = lf + 6;
+                for (i = 0; i < lh; i++) l[mh + i] = t[i];
+                fwd97_1d(l, mh, mh + lh);
+                j = 0;
+                for (i = mh + (mh & 1); i < lh + mh; i += 2) t[j++] = l[i];
+                for (i = mh + 1 - (mh & 1); i < lh + mh; i += 2) t[j++] = l[i];
+            } else {
+                int32_t *t = (int32_t *)plane + (size_t)r * W, *l = li + 6;
+                for (i = 0; i < lh; i++) l[mh + i] = t[i];
+                fwd53_1d(l, mh, mh + lh);
+                j = 0;
+                for (i = mh + (mh & 1); i < lh + mh; i += 2) t[j++] = l[i];
+                for (i = mh + 1 - (mh & 1); i < lh + mh; i += 2) t[j++] = l[i];
+            }
+        }
+    }
+    free(li); free(lf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ tag tree + packet header bits */
+typedef struct TNode { int value, low, known, parent; } TNode;
+typedef struct TagTree { TNode *n; int w, h, count; } TagTree;
+
+static int tt_init(TagTree *t, int w, int h)
+{
+    int lw[32], lh[32], lv = 0, total = 0, i, j, k, base, next;
+    lw[0] = w; lh[0] = h;
+    while (1) {
+        total += lw[lv] * lh[lv];
+        if (lw[lv] <= 1 && lh[lv] <= 1) break;
+        lw[lv + 1] = (lw[lv] + 1) >> 1; lh[lv + 1] = (lh[lv] + 1) >> 1; lv++;
+    }
+    t->n = (TNode *)calloc((size_t)imax(total, 1), sizeof(TNode));
+    if (!t->n) return -1;
+    t->w = w; t->h = h; t->count = total;
+    base = 0;
+    for (k = 0; k <= lv; k++) {
+        next = base + lw[k] * lh[k];
+        for (i = 0; i < lh[k]; i++)
+            for (j = 0; j < lw[k]; j++)
+                t->n[base + i * lw[k] + j].parent = (k == lv) ? -1 : next + (i >> 1) * lw[k + 1] + (j >> 1);
+        base = next;
+    }
+    for (i = 0; i < total; i++) t->n[i].value = 0x7FFFFFFF;
+    return 0;
+}
+static void tt_set(TagTree *t, int leaf, int value)
+{
+    int n = leaf;
+    while (n >= 0 && t->n[n].value > value) { t->n[n].value = value; n = t->n[n].parent; }
+}
+
+typedef struct BitW { Buf *b; uint32_t tmp; int nbits, maxbits; } BitW;
+static void bw_init(BitW *w, Buf *b) { w->b = b; w->tmp = 0; w->nbits = 0; w->maxbits = 8; }
+static void bw_bit(BitW *w, int bit)
+{
+    w->tmp = (w->tmp << 1) | (bit & 1);
+    if (++w->nbits == w->maxbits) {
+        buf_u8(w->b, w->tmp);
+        w->maxbits = (w->tmp == 0xFF) ? 7 : 8;
+        w->tmp = 0; w->nbits = 0;
+    }
+}
+static void bw_bits(BitW *w, uint32_t v, int n) { while (n-- > 0) bw_bit(w, (v >> n) & 1); }
+static void bw_flush(BitW *w)
+{
+    if (w->nbits) {
+        w->tmp <<= (w->maxbits - w->nbits);
+        buf_u8(w->b, w->tmp);
+        if (w->tmp == 0xFF) buf_u8(w->b, 0);
+    } else if (w->maxbits == 7) {
+        buf_u8(w->b, 0);               /* last full byte was 0xFF: a stuffed byte must follow */
+    }
+    w->tmp = 0; w->nbits = 0; w->maxbits = 8;
+}
+static void tt_encode(TagTree *t, BitW *w, int leaf, int threshold)
+{
+    int stk[32], sp = 0, n = leaf, low = 0;
+    while (n >= 0) { stk[sp++] = n; n = t->n[n].parent; }
+    while (sp-- > 0) {
+        TNode *nd = &t->n[stk[sp]];
+        if (low > nd->low) nd->low = low; else low = nd->low;
+        while (low < threshold) {
+            if (low >= nd->value) {
+                if (!nd->known) { bw_bit(w, 1); nd->known = 1; }
+                break;
+            }
+            bw_bit(w, 0);
+            low++;
+        }
+        nd->low = low;
+    }
+}
+
+/* ------------------------------------------------------------------ codestream structure */
+typedef struct ECblk {
+    int x0, x1, y0, y1;        /* band coordinates */
+    Buf data;                  /* Dcup || Dref */
+    int lcup, lref, npasses;   /* npasses includes placeholder passes */
+    int zbp;
+    int included;
+} ECblk;
+typedef struct EPrec { int ncw, nch; ECblk *cb; TagTree incl, zbp; } EPrec;
+typedef struct EBand { int x0, x1, y0, y1; int xob, yob; int cbw, cbh; float fstep; int expn, mant, M_b; EPrec *prec; int offx, offy; } EBand;
+typedef struct ERes  { int x0, x1, y0, y1; int ppx, ppy, npx, npy; int nbands; EBand band[3]; } ERes;
+typedef struct EComp { int x0, x1, y0, y1; ERes *res; void *plane; } EComp;
+
+static void free_comp(EComp *c, int nres)
+{
+    int r, b, p, k;
+    if (c->res)
+        for (r = 0; r < nres; r++)
+            for (b = 0; b < c->res[r].nbands; b++) {
+                EBand *bd = &c->res[r].band[b];
+                if (!bd->prec) continue;
+                for (p = 0; p < c->res[r].npx * c->res[r].npy; p++) {
+                    EPrec *pr = &bd->prec[p];
+                    for (k = 0; k < pr->ncw * pr->nch; k++) free(pr->cb[k].data.p);
+                    free(pr->cb); free(pr->incl.n); free(pr->zbp.n);
+                }
+                free(bd->prec);
+            }
+    free(c->res);
+    free(c->plane);
+    memset(c, 0, sizeof(*c));
+}
+
+static float exp2fi(int x) { union { uint32_t i; float f; } v; v.i = (uint32_t)(x + 127) << 23; return v.f; }
+
+/* Encode one codeblock out of the (quantised, sign-magnitude) band samples */
+static int encode_block(const htj2k_enc_params *P, const EBand *bd, ECblk *cb,
+                        const int32_t *qplane, int pstride, int *need_Mb)
+{
+    int w = cb->x1 - cb->x0, h = cb->y1 - cb->y0, x, y, ret, maxU = 0;
+    int p = P->passes > 1 ? 1 : 0;            /* cleanup bit-plane */
+    uint32_t *full = (uint32_t *)malloc(sizeof(uint32_t) * w * h);
+    uint32_t *mag  = (uint32_t *)malloc(sizeof(uint32_t) * w * h);
+    uint8_t  *sgn  = (uint8_t *)malloc((size_t)w * h);
+    int any = 0, any_full = 0;
+    const int32_t *src = qplane + (size_t)(bd->offy + cb->y0 - bd->y0) * pstride + (bd->offx + cb->x0 - bd->x0);
+
+    if (!full || !mag || !sgn) { free(full); free(mag); free(sgn); return -1; }
+    for (y = 0; y < h; y++)
+        for (x = 0; x < w; x++) {
+            int32_t v = src[(size_t)y * pstride + x];
+            uint32_t m = (uint32_t)(v < 0 ? -(int64_t)v : v);
+            full[y * w + x] = m;
+            mag[y * w + x]  = m >> p;
+            sgn[y * w + x]  = v < 0;
+            any |= (m >> p) != 0;
+            any_full |= m != 0;
+        }
+    cb->included = 0; cb->npasses = 0; cb->lcup = cb->lref = 0;
+    (void)any_full;
+    if (!any && !P->force_include) { free(full); free(mag); free(sgn); return 0; }
+    /* (an all-zero cleanup pass is legal: MEL codes every quad as empty) */
+    ret = ht_cleanup_encode(mag, sgn, w, h, w, &cb->data, &maxU);
+    if (ret < 0) { free(full); free(mag); free(sgn); return ret; }
+    cb->lcup = (int)cb->data.n;
+    cb->npasses = 1;
+    if (P->passes > 1) {
+        ret = ht_refine_encode(full, sgn, w, h, w, P->passes, (P->cblk_style & 0x08) != 0, &cb->data);
+        if (ret < 0) { free(full); free(mag); free(sgn); return ret; }
+        cb->lref = (int)cb->data.n - cb->lcup;
+        cb->npasses = P->passes;
+    }
+    cb->npasses += 3 * P->placeholder_sets;
+    cb->included = 1;
+    /* decoder: U <= S_blk + 1 with S_blk = p0 + zbp and pLSB = 30 - S_blk = 31 - M_b + p
+     * => S_blk = M_b - 1 - p  => need M_b >= maxU + p  (at least 1) */
+    if (maxU + p > *need_Mb) *need_Mb = maxU + p;
+    free(full); free(mag); free(sgn);
+    return 0;
+}
+
+static void write_packet(const htj2k_enc_params *P, ERes *rs, int precno, Buf *out, int *pktno)
+{
+    Buf hdr = { 0 };
+    BitW bw;
+    int b, k, any = 0;
+
+    for (b = 0; b < rs->nbands; b++) {
+        EBand *bd = &rs->band[b];
+        if (bd->x0 == bd->x1 || bd->y0 == bd->y1) continue;
+        for (k = 0; k < bd->prec[precno].ncw * bd->prec[precno].nch; k++)
+            any |= bd->prec[precno].cb[k].included;
+    }
+    if (P->sop) {
+        buf_u16(out, 0xFF91); buf_u16(out, 4); buf_u16(out, (unsigned)(*pktno & 0xFFFF));
+    }
+    (*pktno)++;
+    bw_init(&bw, &hdr);
+    if (!any && !P->never_empty_packets) {
+        bw_bit(&bw, 0);
+        bw_flush(&bw);
+        buf_put(out, hdr.p, hdr.n);
+        if (P->eph) buf_u16(out, 0xFF92);
+        free(hdr.p);
+        return;
+    }
+    bw_bit(&bw, 1);
+    for (b = 0; b < rs->nbands; b++) {
+        EBand *bd = &rs->band[b];
+        EPrec *pr;
+        if (bd->x0 == bd->x1 || bd->y0 == bd->y1) continue;
+        pr = &bd->prec[precno];
+        for (k = 0; k < pr->ncw * pr->nch; k++) {
+            ECblk *cb = &pr->cb[k];
+            int np, lblock = 3, need, extra;
+            tt_encode(&pr->incl, &bw, k, 1);
+            if (!cb->included) continue;
+            tt_encode(&pr->zbp, &bw, k, cb->zbp + 1);
+            /* number of passes (T.800 Table B.4) */
+            np = cb->npasses;
+            if (np == 1) bw_bit(&bw, 0);
+            else if (np == 2) bw_bits(&bw, 2, 2);
+            else if (np <= 5) { bw_bits(&bw, 3, 2); bw_bits(&bw, (uint32_t)(np - 3), 2); }
+            else if (np <= 36) { bw_bits(&bw, 0xF, 4); bw_bits(&bw, (uint32_t)(np - 6), 5); }
+            else { bw_bits(&bw, 0x1FF, 9); bw_bits(&bw, (uint32_t)(np - 37), 7); }
+            /* HT segment lengths: the first field has lblock + floor(log2(passes in the
+             * first segment incl. placeholders)) bits, refinement has lblock (+1 for 2 passes) */
+            {
+                int z = np - 3 * P->placeholder_sets;          /* real passes 1..3 */
+                int seg1 = np - (z - 1);                        /* placeholders + cleanup */
+                int b1 = 0, b2 = (z == 3) ? 1 : 0;
+                while ((2 << b1) <= seg1) b1++;
+                need = imax(bitlen32((uint32_t)cb->lcup) - b1, z > 1 ? bitlen32((uint32_t)cb->lref) - b2 : 0);
+                extra = imax(0, need - lblock);
+                for (; extra > 0; extra--) { bw_bit(&bw, 1); lblock++; }
+                bw_bit(&bw, 0);
+                bw_bits(&bw, (uint32_t)cb->lcup, lblock + b1);
+                if (z > 1)
+                    bw_bits(&bw, (uint32_t)cb->lref, lblock + b2);
+            }
+        }
+    }
+    bw_flush(&bw);
+    buf_put(out, hdr.p, hdr.n);
+    if (P->eph) buf_u16(out, 0xFF92);
+    for (b = 0; b < rs->nbands; b++) {
+        EBand *bd = &rs->band[b];
+        EPrec *pr;
+        if (bd->x0 == bd->x1 || bd->y0 == bd->y1) continue;
+        pr = &bd->prec[precno];
+        for (k = 0; k < pr->ncw * pr->nch; k++)
+            if (pr->cb[k].included)
+                buf_put(out, pr->cb[k].data.p, pr->cb[k].data.n);
+    }
+    free(hdr.p);
+}
+
+/* step-size exponent/mantissa of band (r, b) */
+static void band_quant(const htj2k_enc_params *P, int c, int r, int b, int NL, int *expn, int *mant)
+{
+    int depth = P->depth[c];
+    int kind = r == 0 ? 0 : b + 1;        /* 0 LL, 1 HL, 2 LH, 3 HH */
+    if (P->transform == 1) {
+        static const int gain[4] = { 0, 1, 1, 2 };
+        *expn = depth + gain[kind] + (P->mct ? 1 : 0) + P->expn_bias;
+        *mant = 0;
+    } else {
+        /* delta_b = qstep * 2^(-level weighting): finer steps at low resolutions */
+        int lvl = r == 0 ? NL : NL - r + 1;
+        double d = P->qstep * pow(2.0, -0.5 * (lvl - 1)) * (kind == 3 ? 1.0 : 1.0);
+        int e;
+        double fr;
+        if (d <= 0) d = 1.0 / 64;
+        /* d = 2^(depth - expn) * (1 + mant/2048) */
+        e = (int)floor(log2(d));
+        fr = d / pow(2.0, e);
+        *mant = (int)floor((fr - 1.0) * 2048.0 + 0.5);
+        if (*mant >= 2048) { *mant = 0; e++; }
+        *expn = depth - e;
+        if (*expn < 0) { *expn = 0; }
+        if (*expn > 31) { *expn = 31; }
+        (void)NL;
+    }
+}
+
+/* the decoder's f_stepsize for this band (jpeg2000.c:214-272 as restated in j2k_parse.c;
+ * duplicated here on purpose so the factory stays independent of the product parser) */
+static float band_fstep(const htj2k_enc_params *P, int c, int r, int b, int NL, int expn, int mant)
+{
+    float f;
+    if (P->transform == 1) return 1.0f;
+    f = exp2fi(P->depth[c] - expn);
+    f = (float)(f * (mant / 2048.0 + 1.0));
+    {
+        int lband = 0;
+        switch (b + (r > 0)) {
+        case 1: case 2: f *= X97 * 2; lband = 1; break;
+        case 3: f *= X97 * X97 * 4; break;
+        }
+        f = (float)(f * pow(K97, 2 * ((NL + 1) - r) + lband - 2));
+    }
+    return f;
+}
+
+int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8_t **out_buf, size_t *out_len)
+{
+    Buf out = { 0 };
+    int NL = P->nlevels, nres = NL + 1;
+    int X0 = P->x_off, Y0 = P->y_off, X1 = P->x_off + P->width, Y1 = P->y_off + P->height;
+    int TW = P->tile_w > 0 ? P->tile_w : X1 - P->tx_off, TH = P->tile_h > 0 ? P->tile_h : Y1 - P->ty_off;
+    int ntx = ceil_div(X1 - P->tx_off, TW), nty = ceil_div(Y1 - P->ty_off, TH);
+    int c, r, b, t, ret = 0, guard = P->guard_bits > 0 ? P->guard_bits : 2;
+    int is_float = P->transform == 0;
+    int expn[4][34 * 3], mant[4][34 * 3];
+    Buf *tile_bufs = (Buf *)calloc((size_t)ntx * nty, sizeof(Buf));
+    int need_Mb_excess = 0;   /* how many bits M_b falls short of, over all bands */
+
+    *out_buf = NULL; *out_len = 0;
+    if (!tile_bufs) return -1;
+    if (P->ncomp < 1 || P->ncomp > 4 || NL < 0 || NL > 32) { free(tile_bufs); return -22; }
+
+    for (c = 0; c < P->ncomp; c++)
+        for (r = 0; r < nres; r++)
+            for (b = 0; b < (r ? 3 : 1); b++) {
+                int g = r ? 3 * (r - 1) + 1 + b : 0;
+                band_quant(P, c, r, b, NL, &expn[c][g], &mant[c][g]);
+            }
+
+    /* ---- encode every tile into its own buffer (so that Psot is known) ---- */
+    for (t = 0; t < ntx * nty && !ret; t++) {
+        int tx = t % ntx, ty = t / ntx;
+        int tx0 = imax(P->tx_off + tx * TW, X0), tx1 = imin(P->tx_off + (tx + 1) * TW, X1);
+        int ty0 = imax(P->ty_off + ty * TH, Y0), ty1 = imin(P->ty_off + (ty + 1) * TH, Y1);
+        EComp comp[4];
+        Buf *tb = &tile_bufs[t];
+        int pktno = 0;
+        memset(comp, 0, sizeof(comp));
+
+        /* tile-component planes: level shift (+ forward MCT) and forward DWT */
+        for (c = 0; c < P->ncomp && !ret; c++) {
+            EComp *cp = &comp[c];
+            int dx = P->dx[c] ? P->dx[c] : 1, dy = P->dy[c] ? P->dy[c] : 1;
+            int cw_img = ceil_div(X1, dx) - ceil_div(X0, dx);     /* component width in the source array */
+            int cx0 = ceil_div(X0, dx), cy0 = ceil_div(Y0, dy), x, y;
+            size_t n;
+            cp->x0 = ceil_div(tx0, dx); cp->x1 = ceil_div(tx1, dx);
+            cp->y0 = ceil_div(ty0, dy); cp->y1 = ceil_div(ty1, dy);
+            n = (size_t)imax(cp->x1 - cp->x0, 0) * imax(cp->y1 - cp->y0, 0);
+            cp->plane = calloc(n ? n : 1, 4);
+            if (!cp->plane) { ret = -1; break; }
+            for (y = cp->y0; y < cp->y1; y++)
+                for (x = cp->x0; x < cp->x1; x++) {
+                    int32_t v = comps[c][(size_t)(y - cy0) * cw_img + (x - cx0)];
+                    if (!P->sgnd[c]) v -= 1 << (P->depth[c] - 1);
+                    if (is_float) ((float *)cp->plane)[(size_t)(y - cp->y0) * (cp->x1 - cp->x0) + (x - cp->x0)] = (float)v;
+                    else          ((int32_t *)cp->plane)[(size_t)(y - cp->y0) * (cp->x1 - cp->x0) + (x - cp->x0)] = v;
+                }
+        }
+        if (!ret && P->mct && P->ncomp >= 3) {
+            size_t n = (size_t)(comp[0].x1 - comp[0].x0) * (comp[0].y1 - comp[0].y0), i;
+            if (is_float) {
+                float *R = (float *)comp[0].plane, *G = (float *)comp[1].plane, *B = (float *)comp[2].plane;
+                for (i = 0; i < n; i++) {
+                    float rr = R[i], g = G[i], bb = B[i];
+                    R[i] =  0.299f * rr + 0.587f * g + 0.114f * bb;
+                    G[i] = -0.168736f * rr - 0.331264f * g + 0.5f * bb;
+                    B[i] =  0.5f * rr - 0.418688f * g - 0.081312f * bb;
+                }
+            } else {
+                int32_t *R = (int32_t *)comp[0].plane, *G = (int32_t *)comp[1].plane, *B = (int32_t *)comp[2].plane;
+                for (i = 0; i < n; i++) {
+                    int32_t rr = R[i], g = G[i], bb = B[i];
+                    R[i] = (rr + 2 * g + bb) >> 2;
+                    G[i] = bb - g;
+                    B[i] = rr - g;
+                }
+            }
+        }
+        for (c = 0; c < P->ncomp && !ret; c++) {
+            EComp *cp = &comp[c];
+            if (cp->x1 > cp->x0 && cp->y1 > cp->y0)
+                ret = fwd_dwt(cp->plane, is_float, cp->x0, cp->x1, cp->y0, cp->y1, NL);
+        }
+        /* geometry (T.800 Annex B.5-B.7) + quantisation + block coding */
+        for (c = 0; c < P->ncomp && !ret; c++) {
+            EComp *cp = &comp[c];
+            int W = cp->x1 - cp->x0;
+            int32_t *q = NULL;
+            cp->res = (ERes *)calloc(nres, sizeof(ERes));
+            if (!cp->res) { ret = -1; break; }
+            if (is_float) {
+                q = (int32_t *)calloc((size_t)imax(W, 1) * imax(cp->y1 - cp->y0, 1), 4);
+                if (!q) { ret = -1; break; }
+            }
+            for (r = 0; r < nres && !ret; r++) {
+                ERes *rs = &cp->res[r];
+                int nd = NL - r;     /* remaining decompositions */
+                rs->x0 = ceil_shift(cp->x0, nd); rs->x1 = ceil_shift(cp->x1, nd);
+                rs->y0 = ceil_shift(cp->y0, nd); rs->y1 = ceil_shift(cp->y1, nd);
+                rs->ppx = P->nprec ? P->prec_w_log2[imin(r, P->nprec - 1)] : 15;
+                rs->ppy = P->nprec ? P->prec_h_log2[imin(r, P->nprec - 1)] : 15;
+                rs->npx = rs->x1 > rs->x0 ? ceil_shift(rs->x1, rs->ppx) - floor_shift(rs->x0, rs->ppx) : 0;
+                rs->npy = rs->y1 > rs->y0 ? ceil_shift(rs->y1, rs->ppy) - floor_shift(rs->y0, rs->ppy) : 0;
+                rs->nbands = r ? 3 : 1;
+                for (b = 0; b < rs->nbands && !ret; b++) {
+                    EBand *bd = &rs->band[b];
+                    int g = r ? 3 * (r - 1) + 1 + b : 0;
+                    int lvl = r ? NL - r + 1 : NL;
+                    int pbx = r ? rs->ppx - 1 : rs->ppx, pby = r ? rs->ppy - 1 : rs->ppy;
+                    int px, py, need_Mb = 1;
+                    bd->xob = r ? ((b + 1) & 1) : 0;
+                    bd->yob = r ? (((b + 1) >> 1) & 1) : 0;
+                    if (r == 0) {
+                        bd->x0 = rs->x0; bd->x1 = rs->x1; bd->y0 = rs->y0; bd->y1 = rs->y1;
+                    } else {
+                        bd->x0 = ceil_shift(cp->x0 - (bd->xob << (lvl - 1)), lvl);
+                        bd->x1 = ceil_shift(cp->x1 - (bd->xob << (lvl - 1)), lvl);
+                        bd->y0 = ceil_shift(cp->y0 - (bd->yob << (lvl - 1)), lvl);
+                        bd->y1 = ceil_shift(cp->y1 - (bd->yob << (lvl - 1)), lvl);
+                    }
+                    /* Mallat placement: high bands sit after the low part of the same level */
+                    bd->offx = bd->xob ? (ceil_shift(cp->x1, lvl) - ceil_shift(cp->x0, lvl)) : 0;
+                    bd->offy = bd->yob ? (ceil_shift(cp->y1, lvl) - ceil_shift(cp->y0, lvl)) : 0;
+                    bd->cbw = imin(P->cb_w_log2, pbx);
+                    bd->cbh = imin(P->cb_h_log2, pby);
+                    bd->expn = expn[c][g]; bd->mant = mant[c][g];
+                    bd->M_b = bd->expn + guard - 1;
+                    bd->fstep = band_fstep(P, c, r, b, NL, bd->expn, bd->mant);
+                    if (rs->npx * rs->npy == 0) continue;
+                    bd->prec = (EPrec *)calloc((size_t)rs->npx * rs->npy, sizeof(EPrec));
+                    if (!bd->prec) { ret = -1; break; }
+                    /* quantise the band (9/7): deadzone, sign-magnitude */
+                    if (is_float) {
+                        int x, y;
+                        for (y = 0; y < bd->y1 - bd->y0; y++)
+                            for (x = 0; x < bd->x1 - bd->x0; x++) {
+                                size_t o = (size_t)(bd->offy + y) * W + bd->offx + x;
+                                float v = ((float *)cp->plane)[o];
+                                double m = floor(fabs((double)v) / bd->fstep);
+                                if (m > 2147483000.0) m = 2147483000.0;
+                                q[o] = v < 0 ? -(int32_t)m : (int32_t)m;
+                            }
+                    }
+                    for (py = 0; py < rs->npy && !ret; py++)
+                        for (px = 0; px < rs->npx && !ret; px++) {
+                            EPrec *pr = &bd->prec[py * rs->npx + px];
+                            int prx0 = (floor_shift(rs->x0, rs->ppx) + px) << pbx, pry0 = (floor_shift(rs->y0, rs->ppy) + py) << pby;
+                            int px0 = imax(prx0, bd->x0), px1 = imin(prx0 + (1 << pbx), bd->x1);
+                            int py0 = imax(pry0, bd->y0), py1 = imin(pry0 + (1 << pby), bd->y1);
+                            int i, j;
+                            if (px1 <= px0 || py1 <= py0) { pr->ncw = pr->nch = 0; }
+                            else {
+                                pr->ncw = ceil_shift(px1, bd->cbw) - floor_shift(px0, bd->cbw);
+                                pr->nch = ceil_shift(py1, bd->cbh) - floor_shift(py0, bd->cbh);
+                            }
+                            pr->cb = (ECblk *)calloc((size_t)imax(pr->ncw * pr->nch, 1), sizeof(ECblk));
+                            if (!pr->cb || tt_init(&pr->incl, imax(pr->ncw, 1), imax(pr->nch, 1)) ||
+                                tt_init(&pr->zbp, imax(pr->ncw, 1), imax(pr->nch, 1))) { ret = -1; break; }
+                            for (j = 0; j < pr->nch && !ret; j++)
+                                for (i = 0; i < pr->ncw && !ret; i++) {
+                                    ECblk *cb = &pr->cb[j * pr->ncw + i];
+                                    int gx = (floor_shift(px0, bd->cbw) + i) << bd->cbw;
+                                    int gy = (floor_shift(py0, bd->cbh) + j) << bd->cbh;
+                                    cb->x0 = imax(gx, px0); cb->x1 = imin(gx + (1 << bd->cbw), px1);
+                                    cb->y0 = imax(gy, py0); cb->y1 = imin(gy + (1 << bd->cbh), py1);
+                                    ret = encode_block(P, bd, cb, is_float ? q : (int32_t *)cp->plane, W, &need_Mb);
+                                }
+                        }
+                    if (need_Mb > bd->M_b) need_Mb_excess = imax(need_Mb_excess, need_Mb - bd->M_b);
+                    /* zbp and tag trees */
+                    for (py = 0; py < rs->npy * rs->npx && !ret; py++) {
+                        EPrec *pr = &bd->prec[py];
+                        int k;
+                        for (k = 0; k < pr->ncw * pr->nch; k++) {
+                            ECblk *cb = &pr->cb[k];
+                            int pp = P->passes > 1 ? 1 : 0;
+                            cb->zbp = bd->M_b - 1 - pp - P->placeholder_sets;
+                            tt_set(&pr->incl, k, cb->included ? 0 : 1);
+                            if (cb->included) tt_set(&pr->zbp, k, imax(cb->zbp, 0));
+                            if (cb->included && cb->zbp < 0) ret = -5;
+                        }
+                    }
+                }
+            }
+            free(q);
+        }
+        if (!ret && need_Mb_excess) ret = -4;
+
+        /* ---- packets in progression order (T.800 B.12) ---- */
+        if (!ret) {
+            int prog = P->prog_order;
+            if (prog == 0) {            /* LRCP (1 layer) */
+                for (r = 0; r < nres; r++)
+                    for (c = 0; c < P->ncomp; c++) {
+                        ERes *rs = &comp[c].res[r];
+                        int p;
+                        for (p = 0; p < rs->npx * rs->npy; p++) write_packet(P, rs, p, tb, &pktno);
+                    }
+            } else if (prog == 1) {     /* RLCP */
+                for (r = 0; r < nres; r++)
+                    for (c = 0; c < P->ncomp; c++) {
+                        ERes *rs = &comp[c].res[r];
+                        int p;
+                        for (p = 0; p < rs->npx * rs->npy; p++) write_packet(P, rs, p, tb, &pktno);
+                    }
+            } else {
+                /* position-driven orders: visit (y,x) on the finest precinct grid and emit the
+                 * precinct of (c,r) whose top-left corner projects to that position */
+                int x, y, order, *done[4][34];
+                int minsx = 1 << 30, minsy = 1 << 30;
+                for (c = 0; c < P->ncomp; c++)
+                    for (r = 0; r < nres; r++) {
+                        ERes *rs = &comp[c].res[r];
+                        int dx = P->dx[c] ? P->dx[c] : 1, dy = P->dy[c] ? P->dy[c] : 1;
+                        done[c][r] = (int *)calloc((size_t)imax(rs->npx * rs->npy, 1), sizeof(int));
+                        if (rs->ppx + NL - r < 30) minsx = imin(minsx, dx << (rs->ppx + NL - r));
+                        if (rs->ppy + NL - r < 30) minsy = imin(minsy, dy << (rs->ppy + NL - r));
+                    }
+                if (minsx > (1 << 29)) minsx = 1 << 29;
+                if (minsy > (1 << 29)) minsy = 1 << 29;
+                (void)order;
+#define EMIT_AT(c_, r_) do {                                                                         \
+                    ERes *rs = &comp[c_].res[r_];                                                   \
+                    int dx = P->dx[c_] ? P->dx[c_] : 1, dy = P->dy[c_] ? P->dy[c_] : 1;             \
+                    int nd = NL - (r_);                                                             \
+                    int64_t sx = (int64_t)dx << (rs->ppx + nd), sy = (int64_t)dy << (rs->ppy + nd); \
+                    if (rs->npx * rs->npy == 0) break;                                              \
+                    if (!((y % sy == 0) || (y == ty0 && (((int64_t)rs->y0 << nd) % ((int64_t)1 << (rs->ppy + nd)))))) break; \
+                    if (!((x % sx == 0) || (x == tx0 && (((int64_t)rs->x0 << nd) % ((int64_t)1 << (rs->ppx + nd)))))) break; \
+                    {                                                                               \
+                        int pi = floor_shift(ceil_div(x, dx << nd), rs->ppx) - floor_shift(rs->x0, rs->ppx); \
+                        int pj = floor_shift(ceil_div(y, dy << nd), rs->ppy) - floor_shift(rs->y0, rs->ppy); \
+                        if (pi < 0 || pj < 0 || pi >= rs->npx || pj >= rs->npy) break;              \
+                        if (done[c_][r_][pj * rs->npx + pi]) break;                                 \
+                        done[c_][r_][pj * rs->npx + pi] = 1;                                        \
+                        write_packet(P, rs, pj * rs->npx + pi, tb, &pktno);                         \
+                    }                                                                               \
+                } while (0)
+                if (prog == 2) {        /* RPCL */
+                    for (r = 0; r < nres; r++)
+                        for (y = ty0; y < ty1; y = (y / minsy + 1) * minsy)
+                            for (x = tx0; x < tx1; x = (x / minsx + 1) * minsx)
+                                for (c = 0; c < P->ncomp; c++) EMIT_AT(c, r);
+                } else if (prog == 3) { /* PCRL */
+                    for (y = ty0; y < ty1; y = (y / minsy + 1) * minsy)
+                        for (x = tx0; x < tx1; x = (x / minsx + 1) * minsx)
+                            for (c = 0; c < P->ncomp; c++)
+                                for (r = 0; r < nres; r++) EMIT_AT(c, r);
+                } else {                /* CPRL */
+                    for (c = 0; c < P->ncomp; c++)
+                        for (y = ty0; y < ty1; y = (y / minsy + 1) * minsy)
+                            for (x = tx0; x < tx1; x = (x / minsx + 1) * minsx)
+                                for (r = 0; r < nres; r++) EMIT_AT(c, r);
+                }
+                for (c = 0; c < P->ncomp; c++)
+                    for (r = 0; r < nres; r++) free(done[c][r]);
+            }
+        }
+        for (c = 0; c < P->ncomp; c++) free_comp(&comp[c], nres);
+        if (tb->oom) ret = -1;
+    }
+    if (ret) goto fail;
+
+    /* ---- main header ---- */
+    buf_u16(&out, 0xFF4F);
+    buf_u16(&out, 0xFF51); buf_u16(&out, 38 + 3 * P->ncomp);
+    buf_u16(&out, P->rsiz);
+    buf_u32(&out, (uint32_t)X1); buf_u32(&out, (uint32_t)Y1);
+    buf_u32(&out, (uint32_t)X0); buf_u32(&out, (uint32_t)Y0);
+    buf_u32(&out, (uint32_t)TW); buf_u32(&out, (uint32_t)TH);
+    buf_u32(&out, (uint32_t)P->tx_off); buf_u32(&out, (uint32_t)P->ty_off);
+    buf_u16(&out, P->ncomp);
+    for (c = 0; c < P->ncomp; c++) {
+        buf_u8(&out, (P->depth[c] - 1) | (P->sgnd[c] ? 0x80 : 0));
+        buf_u8(&out, P->dx[c] ? P->dx[c] : 1);
+        buf_u8(&out, P->dy[c] ? P->dy[c] : 1);
+    }
+    /* CAP: Part 15; Ccap15 bit 5 = HTIRV when 9/7 is used; MAGB field from the largest M_b */
+    {
+        int maxMb = 1, Pm;
+        for (c = 0; c < P->ncomp; c++)
+            for (r = 0; r < 3 * NL + 1; r++)
+                maxMb = imax(maxMb, expn[c][r] + guard - 1);
+        Pm = maxMb <= 8 ? 0 : (maxMb < 28 ? maxMb - 8 : 13 + (maxMb >> 2));
+        if (Pm > 31) Pm = 31;
+        buf_u16(&out, 0xFF50); buf_u16(&out, 8); buf_u32(&out, 0x00020000);
+        buf_u16(&out, (unsigned)((P->transform == 0 ? 0x20 : 0) | (Pm & 0x1F) | (P->cap_extra_bits & 0xF800)));
+    }
+    buf_u16(&out, 0xFF52); buf_u16(&out, 12 + (P->nprec ? nres : 0));
+    buf_u8(&out, (P->nprec ? 1 : 0) | (P->sop ? 2 : 0) | (P->eph ? 4 : 0));
+    buf_u8(&out, P->prog_order);
+    buf_u16(&out, 1);
+    buf_u8(&out, P->mct ? 1 : 0);
+    buf_u8(&out, NL);
+    buf_u8(&out, P->cb_w_log2 - 2); buf_u8(&out, P->cb_h_log2 - 2);
+    buf_u8(&out, 0x40 | (P->cblk_style & 0x08));
+    buf_u8(&out, P->transform);
+    if (P->nprec)
+        for (r = 0; r < nres; r++)
+            buf_u8(&out, (P->prec_h_log2[imin(r, P->nprec - 1)] << 4) | P->prec_w_log2[imin(r, P->nprec - 1)]);
+    /* QCD from component 0, QCC for components whose exponents differ */
+    for (c = 0; c < P->ncomp; c++) {
+        int nb = 3 * NL + 1, same = 1, g;
+        if (c > 0) {
+            for (g = 0; g < nb; g++) same &= expn[c][g] == expn[0][g] && mant[c][g] == mant[0][g];
+            if (same) continue;
+            buf_u16(&out, 0xFF5D);
+            buf_u16(&out, (P->transform == 1 ? 4 + nb : 4 + 2 * nb));
+            buf_u8(&out, c);
+        } else {
+            buf_u16(&out, 0xFF5C);
+            buf_u16(&out, (P->transform == 1 ? 3 + nb : 3 + 2 * nb));
+        }
+        buf_u8(&out, (guard << 5) | (P->transform == 1 ? 0 : 2));
+        for (g = 0; g < nb; g++) {
+            if (P->transform == 1) buf_u8(&out, expn[c][g] << 3);
+            else buf_u16(&out, (expn[c][g] << 11) | mant[c][g]);
+        }
+    }
+    if (P->comment) {
+        size_t n = strlen(P->comment);
+        buf_u16(&out, 0xFF64); buf_u16(&out, (unsigned)(4 + n)); buf_u16(&out, 1);
+        buf_put(&out, P->comment, n);
+    }
+    /* ---- tiles (optionally split into two tile-parts at a packet-agnostic byte boundary
+     *      is not possible, so tile-parts are only emitted whole) ---- */
+    for (t = 0; t < ntx * nty; t++) {
+        Buf *tb = &tile_bufs[t];
+        buf_u16(&out, 0xFF90); buf_u16(&out, 10); buf_u16(&out, t);
+        buf_u32(&out, P->psot_zero && t == ntx * nty - 1 ? 0 : (uint32_t)(tb->n + 14));
+        buf_u8(&out, 0); buf_u8(&out, 1);
+        buf_u16(&out, 0xFF93);
+        buf_put(&out, tb->p, tb->n);
+    }
+    buf_u16(&out, 0xFFD9);
+    if (out.oom) { ret = -1; goto fail; }
+    for (t = 0; t < ntx * nty; t++) free(tile_bufs[t].p);
+    free(tile_bufs);
+    *out_buf = out.p; *out_len = out.n;
+    return 0;
+fail:
+    for (t = 0; t < ntx * nty; t++) free(tile_bufs[t].p);
+    free(tile_bufs);
+    free(out.p);
+    return ret;
+}
+
+void htj2k_enc_free(uint8_t *p) { free(p); }
+
+/* Encode one raw HT cleanup (+refinement) segment, for block-level unit tests.
+ * vals: w*h signed quantisation indices.  Returns Dcup||Dref and the lengths. */
+int htj2k_encode_block(const int32_t *vals, int w, int h, int passes, int causal,
+                       uint8_t **out, int *lcup, int *lref, int *max_U)
+{
+    Buf b = { 0 };
+    int p = passes > 1 ? 1 : 0, i, ret;
+    uint32_t *full = (uint32_t *)malloc(sizeof(uint32_t) * w * h);
+    uint32_t *mag  = (uint32_t *)malloc(sizeof(uint32_t) * w * h);
+    uint8_t  *sgn  = (uint8_t *)malloc((size_t)w * h);
+    if (!full || !mag || !sgn) { free(full); free(mag); free(sgn); return -1; }
+    for (i = 0; i < w * h; i++) {
+        uint32_t m = (uint32_t)(vals[i] < 0 ? -(int64_t)vals[i] : vals[i]);
+        full[i] = m; mag[i] = m >> p; sgn[i] = vals[i] < 0;
+    }
+    ret = ht_cleanup_encode(mag, sgn, w, h, w, &b, max_U);
+    *lcup = (int)b.n; *lref = 0;
+    if (!ret && passes > 1) {
+        ret = ht_refine_encode(full, sgn, w, h, w, passes, causal, &b);
+        *lref = (int)b.n - *lcup;
+    }
+    free(full); free(mag); free(sgn);
+    if (ret || b.oom) { free(b.p); return ret ? ret : -1; }
+    /* pad so that decoders may over-read a few bytes */
+    for (i = 0; i < 8; i++) buf_u8(&b, 0);
+    *out = b.p;
+    return 0;
+}
