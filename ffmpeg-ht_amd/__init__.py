@@ -1,0 +1,277 @@
+"""ffmpeg-ht_amd -- thin Python (ctypes) binding of the MI355X-native HTJ2K decode library.
+
+The product is the C-ABI shared library `libhtj2k_amd.so` (include/htj2k_amd.h): host C
+parser + HIP kernels behind the plugin surface of FFmpeg's `ff_jpeg2000_decoder`
+(libavcodec/jpeg2000dec.c:2926-2939).  This module only loads it for tests, bench.py and
+scripting; it contains no decoding logic and NO fallback: if the library or a GPU is
+missing, construction fails loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhtj2k_amd.so")
+
+ERR_NAMES = {-0x41444E49: "INVALIDDATA", -0x45574150: "PATCHWELCOME", -0x21475542: "BUG", -0x20545845: "EXTERNAL",
+             -12: "ENOMEM", -22: "EINVAL", -38: "ENOSYS"}
+DWT97, DWT53, DWT97_INT = 0, 1, 2
+
+PIX_NAMES = ["pal8", "rgb24", "rgba", "rgb48le", "rgba64le", "gray", "ya8", "gray16le", "ya16le",
+             "yuv410p", "yuv411p", "yuva420p", "yuv420p", "yuv422p", "yuva422p", "yuv440p", "yuv444p", "yuva444p",
+             "yuv420p9le", "yuv422p9le", "yuv444p9le", "yuva420p9le", "yuva422p9le", "yuva444p9le",
+             "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuva420p10le", "yuva422p10le", "yuva444p10le",
+             "yuv420p12le", "yuv422p12le", "yuv444p12le", "yuv420p14le", "yuv422p14le", "yuv444p14le",
+             "yuv420p16le", "yuv422p16le", "yuv444p16le", "yuva420p16le", "yuva422p16le", "yuva444p16le", "xyz12le"]
+
+
+class Htj2kError(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__("%s failed: %s (%d)" % (what or "htj2k", ERR_NAMES.get(code, "?"), code))
+        self.code = code
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("bitexact", ctypes.c_int), ("reduction_factor", ctypes.c_int), ("max_pixels", ctypes.c_int64),
+                ("strict", ctypes.c_int), ("device_id", ctypes.c_int), ("frames_in_flight", ctypes.c_int),
+                ("req_pix_fmt", ctypes.c_int)]
+
+
+class Info(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("pix_fmt", ctypes.c_int),
+                ("bits_per_raw_sample", ctypes.c_int), ("profile", ctypes.c_int), ("lossless", ctypes.c_int),
+                ("sar_num", ctypes.c_int), ("sar_den", ctypes.c_int), ("ncomponents", ctypes.c_int),
+                ("is_ht", ctypes.c_int), ("nplanes", ctypes.c_int), ("plane_width", ctypes.c_int * 4),
+                ("plane_height", ctypes.c_int * 4), ("plane_bytes_per_sample", ctypes.c_int * 4),
+                ("has_palette", ctypes.c_int)]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p * 4), ("linesize", ctypes.c_int * 4), ("width", ctypes.c_int),
+                ("height", ctypes.c_int), ("pix_fmt", ctypes.c_int)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("n_codeblocks", ctypes.c_int), ("n_block_errors", ctypes.c_int), ("ms_parse", ctypes.c_float),
+                ("ms_h2d", ctypes.c_float), ("ms_kernels", ctypes.c_float), ("ms_d2h", ctypes.c_float),
+                ("ms_ht", ctypes.c_float), ("ms_idwt", ctypes.c_float), ("ms_pack", ctypes.c_float)]
+
+
+class BlockDesc(ctypes.Structure):
+    """struct J2kBlock (csrc/j2k_plan.h): one codeblock descriptor, 32 bytes"""
+    _fields_ = [("data_off", ctypes.c_uint32), ("plane_off", ctypes.c_uint32), ("lcup", ctypes.c_uint16),
+                ("lref", ctypes.c_uint16), ("w", ctypes.c_uint16), ("h", ctypes.c_uint16), ("stride", ctypes.c_uint16),
+                ("npasses", ctypes.c_uint8), ("zbp", ctypes.c_uint8), ("M_b", ctypes.c_uint8), ("flags", ctypes.c_uint8),
+                ("roi_shift", ctypes.c_uint8), ("tcomp", ctypes.c_uint8), ("f_step", ctypes.c_float),
+                ("i_step", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(BlockDesc) == 32
+
+EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_decode", "htj2k_job_parse",
+           "htj2k_job_upload", "htj2k_job_run", "htj2k_job_download", "htj2k_job_wait", "htj2k_job_info",
+           "htj2k_job_bytes_consumed", "htj2k_job_free", "htj2k_job_num_tilecomps", "htj2k_job_tilecomp_dims",
+           "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
+           "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_job_block_errors",
+           "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name"]
+
+_lib = None
+
+
+def load_library():
+    """Load libhtj2k_amd.so.  Raises if it has not been built: there is no other implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhtj2k_amd.so is not built (run `make lib` / __graft_entry__.build()); "
+                              "this package has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        L.htj2k_version.restype = ctypes.c_char_p
+        L.htj2k_device_name.restype = ctypes.c_char_p
+        L.htj2k_device_name.argtypes = [ctypes.c_void_p]
+        L.htj2k_job_device_plane.restype = ctypes.c_void_p
+        _lib = L
+    return _lib
+
+
+def _check(r, what):
+    if r < 0:
+        raise Htj2kError(r, what)
+    return r
+
+
+def _pkt(data):
+    # AVPacket data carries AV_INPUT_BUFFER_PADDING_SIZE (64) zero bytes of padding (libavcodec/defs.h:40)
+    return ctypes.create_string_buffer(bytes(data) + b"\0" * 64, len(data) + 64)
+
+
+class Job:
+    """One frame in the staged pipeline (htj2k_job_*)."""
+
+    def __init__(self, dec):
+        self.dec = dec
+        self.h = ctypes.c_void_p(None)
+        self._buf = None
+
+    def parse(self, data):
+        self._buf = _pkt(data)
+        _check(self.dec.L.htj2k_job_parse(self.dec.h, self._buf, len(data), ctypes.byref(self.h)), "htj2k_job_parse")
+        return self
+
+    def upload(self):
+        _check(self.dec.L.htj2k_job_upload(self.dec.h, self.h), "htj2k_job_upload")
+        return self
+
+    def run(self, stages=7):
+        _check(self.dec.L.htj2k_job_run_stages(self.dec.h, self.h, stages), "htj2k_job_run_stages")
+        return self
+
+    def wait(self):
+        _check(self.dec.L.htj2k_job_wait(self.dec.h, self.h), "htj2k_job_wait")
+        return self
+
+    def info(self):
+        info = Info()
+        _check(self.dec.L.htj2k_job_info(self.h, ctypes.byref(info)), "htj2k_job_info")
+        return info
+
+    def stage_ms(self):
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        _check(self.dec.L.htj2k_job_stage_ms(self.dec.h, self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+               "htj2k_job_stage_ms")
+        return a.value, b.value, c.value
+
+    def num_tilecomps(self):
+        return _check(self.dec.L.htj2k_job_num_tilecomps(self.h), "htj2k_job_num_tilecomps")
+
+    def num_blocks(self):
+        return _check(self.dec.L.htj2k_job_num_blocks(self.h), "htj2k_job_num_blocks")
+
+    def block_errors(self):
+        return _check(self.dec.L.htj2k_job_block_errors(self.dec.h, self.h), "htj2k_job_block_errors")
+
+    def plane(self, tc):
+        w, h, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(self.dec.L.htj2k_job_tilecomp_dims(self.h, tc, ctypes.byref(w), ctypes.byref(h), ctypes.byref(f)),
+               "htj2k_job_tilecomp_dims")
+        a = np.empty((h.value, w.value), dtype=np.float32 if f.value else np.int32)
+        _check(self.dec.L.htj2k_job_read_plane(self.dec.h, self.h, tc, a.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_size_t(a.nbytes)), "htj2k_job_read_plane")
+        return a
+
+    def download(self):
+        info = self.info()
+        planes, fr = alloc_frame(info)
+        _check(self.dec.L.htj2k_job_download(self.dec.h, self.h, ctypes.byref(fr)), "htj2k_job_download")
+        return info, planes_to_arrays(info, planes)
+
+    def free(self):
+        if self.h:
+            self.dec.L.htj2k_job_free(self.dec.h, self.h)
+            self.h = ctypes.c_void_p(None)
+
+
+def alloc_frame(info, align=1):
+    planes, fr = [], Frame()
+    for p in range(info.nplanes):
+        rowbytes = info.plane_width[p] * info.plane_bytes_per_sample[p]
+        ls = -(-rowbytes // align) * align
+        a = np.zeros((info.plane_height[p], ls), dtype=np.uint8)
+        planes.append(a)
+        fr.data[p] = a.ctypes.data
+        fr.linesize[p] = ls
+    return planes, fr
+
+
+def planes_to_arrays(info, planes):
+    out = []
+    for p in range(info.nplanes):
+        rowbytes = info.plane_width[p] * info.plane_bytes_per_sample[p]
+        a = np.ascontiguousarray(planes[p][:, :rowbytes])
+        if info.bits_per_raw_sample > 8:
+            a = a.view(np.uint16)
+        out.append(a.reshape(info.plane_height[p], -1))
+    return out
+
+
+class Decoder:
+    """htj2k_open / htj2k_probe / htj2k_decode / htj2k_close: the FFCodec init/decode/close trio."""
+
+    def __init__(self, device_id=0, bitexact=0, reduction_factor=0, req_pix_fmt=-1, strict=0, max_pixels=0):
+        self.L = load_library()
+        o = Opts()
+        o.device_id = device_id
+        o.bitexact = bitexact
+        o.reduction_factor = reduction_factor
+        o.req_pix_fmt = req_pix_fmt
+        o.strict = strict
+        o.max_pixels = max_pixels
+        self.h = ctypes.c_void_p(None)
+        _check(self.L.htj2k_open(ctypes.byref(o), ctypes.byref(self.h)), "htj2k_open")
+        self._buf = None
+
+    def close(self):
+        if self.h:
+            self.L.htj2k_close(self.h)
+            self.h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        return self.L.htj2k_device_name(self.h).decode()
+
+    def set_int(self, name, value):
+        _check(self.L.htj2k_set_int(self.h, name.encode(), int(value)), "htj2k_set_int")
+
+    def probe(self, data):
+        info = Info()
+        self._buf = _pkt(data)
+        _check(self.L.htj2k_probe(self.h, self._buf, len(data), ctypes.byref(info)), "htj2k_probe")
+        return info
+
+    def decode(self, data, align=1):
+        """-> (info, [plane arrays], bytes_consumed, Stats)"""
+        info = self.probe(data)
+        planes, fr = alloc_frame(info, align)
+        st = Stats()
+        self._buf = _pkt(data)
+        r = _check(self.L.htj2k_decode(self.h, self._buf, len(data), ctypes.byref(fr), ctypes.byref(st)), "htj2k_decode")
+        return info, planes_to_arrays(info, planes), r, st
+
+    def job(self):
+        return Job(self)
+
+    # ---- kernel-level entry points ----
+    def idwt(self, plane, border, levels, type_):
+        a = np.ascontiguousarray(plane).copy()
+        b = (ctypes.c_int * 4)(border[0][0], border[0][1], border[1][0], border[1][1])
+        _check(self.L.htj2k_idwt_plane(self.h, a.ctypes.data_as(ctypes.c_void_p), b, levels, type_), "htj2k_idwt_plane")
+        return a
+
+    def idwt_bench(self, w, h, levels, type_, nplanes=1, iters=10):
+        ms = ctypes.c_float()
+        _check(self.L.htj2k_idwt_bench(self.h, w, h, levels, type_, nplanes, iters, ctypes.byref(ms)), "htj2k_idwt_bench")
+        return ms.value
+
+    def mct(self, type_, p0, p1, p2):
+        a, b, c = (np.ascontiguousarray(x).copy() for x in (p0, p1, p2))
+        _check(self.L.htj2k_mct_planes(self.h, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                       c.ctypes.data_as(ctypes.c_void_p), a.size, type_), "htj2k_mct_planes")
+        return a, b, c
+
+    def ht_blocks(self, descs, pool, nsamples, dtype=np.int32):
+        """descs: list of BlockDesc; pool: bytes.  -> (samples[nsamples], status[n])"""
+        n = len(descs)
+        arr = (BlockDesc * n)(*descs)
+        buf = ctypes.create_string_buffer(bytes(pool) + b"\0" * 64, len(pool) + 64)
+        out = np.full(nsamples, 0x7FFFFFFF if dtype == np.int32 else np.nan, dtype=dtype)
+        status = np.zeros(n, dtype=np.int32)
+        _check(self.L.htj2k_ht_blocks(self.h, arr, n, buf, ctypes.c_size_t(len(pool) + 64),
+                                      out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nsamples),
+                                      status.ctypes.data_as(ctypes.c_void_p)), "htj2k_ht_blocks")
+        return out, status

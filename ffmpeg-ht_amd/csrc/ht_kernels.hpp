@@ -1,0 +1,552 @@
+/*
+ * ht_kernels.hpp -- HT block decoder for gfx950: one 64-lane wavefront per codeblock.
+ *
+ * What it computes is ff_jpeg2000_decode_htj2k() (libavcodec/jpeg2000htdec.c:1188-1336)
+ * followed by dequantization_int / _float / _int_97 (libavcodec/jpeg2000dec.c:2098-2181)
+ * written straight into the tile-component plane at the block's Mallat position
+ * (jpeg2000dec.c:2279-2287).  How it computes it is not the reference's byte-at-a-time
+ * bit buffers:
+ *
+ *   stage 0 (64 lanes)  the three byte streams of the cleanup segment are un-stuffed in
+ *                       parallel into LDS bit arrays: per-byte bit counts (7 after a 0xFF
+ *                       for MagSgn, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
+ *                       >0x8F byte for VLC, :145-201), wave prefix sum -> bit offset of
+ *                       every byte, ds_or into 32-bit words.
+ *   stage 1 (lane 0)    MEL + CxtVLC + U-VLC decode of one quad row (:632-973).  The
+ *                       chain "codeword length -> next codeword position -> context" is
+ *                       inherently serial; the two 1024-entry tables live in LDS.
+ *   stage 2 (64 lanes)  lanes = sample columns of the quad row: exponent predictor kappa
+ *                       from the row above (:855-885), m_n, wave prefix sum -> MagSgn bit
+ *                       offsets, extraction from the LDS bit array, mu/E (:395-427),
+ *                       dequantisation and two coalesced row stores.
+ *   stage 3             SigProp (:1016-1131, serial on bitmaps) and MagRef (:1137-1185,
+ *                       parallel popcount-prefix) when the block carries refinement passes.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "j2k_plan.h"
+
+namespace htj2k {
+
+struct HtLds {
+    uint32_t off_ms, ms_words;        /* un-stuffed MagSgn bits */
+    uint32_t off_vlc, vlc_words;      /* un-stuffed VLC bits (in read order) */
+    uint32_t off_suf, suf_bytes;      /* raw MEL+VLC suffix bytes (MEL reads them serially) */
+    uint32_t off_qinfo, max_qw;       /* 2 x max_qw packed quad symbols (current / previous row) */
+    uint32_t off_E;                   /* 2 x (2*max_qw + 8) exponent bytes */
+    uint32_t off_bm, bm_words;        /* 4 bitmaps of bm_words each (sigma, ref, sign, magref), 0 if unused */
+    uint32_t total;
+};
+
+#define HT_ERR_INVALID 1   /* the reference returns AVERROR_INVALIDDATA; block left zero */
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+/* dequantise one sign-magnitude sample (bit 31 sign, magnitude LSB at 31 - M_b) */
+__device__ __forceinline__ uint32_t ht_dequant(uint32_t smag, int transform, int M_b, int roi_shift,
+                                               float fscale, int i_step)
+{
+    uint32_t mag = smag & 0x7FFFFFFFu;
+    const bool neg = (smag >> 31) != 0;
+    if (roi_shift) {                                   /* jpeg2000htdec.c:1326-1328 */
+        const uint32_t mask = 0xFFFFFFFFu >> (M_b + 1);
+        if ((mag & ~mask) == 0) mag <<= roi_shift;
+    }
+    if (transform == J2K_DWT53) {                      /* dequantization_int */
+        int v = (int)(mag >> (31 - M_b));
+        if (neg) v = -v;
+        if (i_step != 32768) {
+            long long t = (long long)v * i_step;       /* (val * (int64_t)i_stepsize) / 65536, truncating */
+            v = (int)(t < 0 ? -((-t) >> 16) : (t >> 16));
+        }
+        return (uint32_t)v;
+    } else if (transform == J2K_DWT97) {               /* dequantization_float */
+        int v = neg ? -(int)mag : (int)mag;
+        return __float_as_uint((float)v * fscale);
+    } else {                                           /* dequantization_int_97 */
+        int v = neg ? -(int)mag : (int)mag;
+        v = (v + 32) >> 6;
+        long long t = (long long)v * i_step;
+        return (uint32_t)(int)((t + (1 << 15)) >> 16);
+    }
+}
+
+/* serial decoder state of lane 0 */
+struct HtSerial {
+    /* VLC: 64-bit window over the un-stuffed LDS words */
+    uint64_t vbuf; int vbits; uint32_t vword;
+    const uint32_t *vlc; uint32_t vlc_words;
+    /* MEL (jpeg2000htdec.c:429-440, 462-495) */
+    const uint8_t *suf; uint32_t mel_pos, mel_len; uint32_t mel_tmp; int mel_bits;
+    int mel_k, mel_run, mel_one;
+
+    __device__ __forceinline__ void vfill()
+    {
+        if (vbits <= 32) {
+            uint32_t wv = vword < vlc_words ? vlc[vword] : 0u;
+            vword++;
+            vbuf |= (uint64_t)wv << vbits;
+            vbits += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t vpeek(int n) { vfill(); return (uint32_t)vbuf & ((1u << n) - 1); }
+    __device__ __forceinline__ void vdrop(int n) { vbuf >>= n; vbits -= n; }
+    __device__ __forceinline__ uint32_t vget(int n) { uint32_t v = vpeek(n); vdrop(n); return v; }
+
+    __device__ __forceinline__ int mel_bit()
+    {
+        if (mel_bits == 0) {
+            const bool cond = mel_pos < mel_len;
+            mel_bits = (mel_tmp == 0xFF) ? 7 : 8;
+            mel_tmp = cond ? suf[mel_pos] : 0xFFu;
+            mel_pos += cond;
+        }
+        mel_bits--;
+        return (mel_tmp >> mel_bits) & 1;
+    }
+    __device__ __forceinline__ int mel_sym()
+    {
+        static const uint8_t MEL_E[13] = { 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 5 };
+        if (mel_run == 0 && mel_one == 0) {
+            int eval = (0x5433222111000ull >> (4 * mel_k)) & 0xF;   /* MEL_E packed in nibbles */
+            (void)MEL_E;
+            if (mel_bit()) {
+                mel_run = 1 << eval;
+                mel_k = mel_k < 12 ? mel_k + 1 : 12;
+            } else {
+                mel_run = 0;
+                while (eval > 0) { mel_run = 2 * mel_run + mel_bit(); eval--; }
+                mel_run &= 0xFF;                                  /* uint8_t run in the reference */
+                mel_k = mel_k > 0 ? mel_k - 1 : 0;
+                mel_one = 1;
+            }
+        }
+        if (mel_run > 0) { mel_run--; return 0; }
+        mel_one = 0;
+        return 1;
+    }
+    /* U-VLC prefix / suffix / extension, jpeg2000htdec.c:338-388 */
+    __device__ __forceinline__ int upfx()
+    {
+        uint32_t b = vpeek(3);
+        /* value {5,1,2,1,3,1,2,1}, drop {3,1,2,1,3,1,2,1} packed in nibbles, index = 3 peeked bits */
+        int val  = (0x12131215u >> (4 * b)) & 0xF;
+        int drop = (0x12131213u >> (4 * b)) & 0xF;
+        vdrop(drop);
+        return val;
+    }
+    __device__ __forceinline__ int usfx(int pfx)
+    {
+        if (pfx < 3) return 0;
+        if (pfx == 3) return (int)vget(1);
+        return (int)vget(5);
+    }
+    __device__ __forceinline__ int uext(int sfx) { return sfx >= 28 ? (int)vget(4) : 0; }
+};
+
+__device__ __forceinline__ void ht_zero_window(uint32_t *dst, int w, int h, int stride, int lane)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = lane; x < w; x += 64)
+            dst[(size_t)y * stride + x] = 0u;
+}
+
+__device__ __forceinline__ int bm_get(const uint32_t *bm, int idx) { return (bm[idx >> 5] >> (idx & 31)) & 1; }
+
+__global__ void __launch_bounds__(64)
+k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+            uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
+            int *__restrict__ status, HtLds L)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= nblocks) return;
+    const J2kBlock b = blocks[blockIdx.x];
+    const int w = b.w, h = b.h, stride = b.stride;
+    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
+    const int transform = b.flags & 3;
+    uint32_t *dst = coef + b.plane_off;
+
+    if (b.npasses == 0) {                              /* not coded: the reference plane is calloc'ed */
+        ht_zero_window(dst, w, h, stride, lane);
+        return;
+    }
+    /* pass bookkeeping, jpeg2000htdec.c:1240-1264 */
+    const int rem = b.npasses % 3;
+    const int num_plhd = rem ? b.npasses - rem : b.npasses - 3;
+    const int p0 = num_plhd / 3;
+    const int z_blk = b.npasses - num_plhd;
+    const uint32_t Lcup = b.lcup, Lref = b.lref;
+    const uint8_t *D = bytes + b.data_off;
+    const int S_blk = (p0 + b.zbp) & 0xFF;
+    const int pLSB = (30 - S_blk) & 0xFF;
+    const int maxbp = S_blk + 1;                       /* (S_blk - 1) + 2, :605,:1263 */
+    int err = 0;
+    uint32_t Scup = 0, Pcup = 0;
+    if (Lcup < 2) err = HT_ERR_INVALID;                /* :1252 */
+    if (!err) {
+        Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+        if (Scup < 2 || Scup > Lcup || Scup > 4079) err = HT_ERR_INVALID;   /* :1268 */
+        Pcup = Lcup - Scup;
+    }
+    if (!err && maxbp >= 32) err = HT_ERR_INVALID;     /* :617 */
+    /* LDS capacity is sized by the host from the same fields; never index past it */
+    if (!err && ((Pcup * 8 + 31) / 32 + 2 > L.ms_words || (Scup * 8 + 31) / 32 + 2 > L.vlc_words ||
+                 Scup > L.suf_bytes || (uint32_t)qw > L.max_qw))
+        err = HT_ERR_INVALID;
+    if (err) {
+        ht_zero_window(dst, w, h, stride, lane);
+        if (lane == 0) status[blockIdx.x] = err;
+        return;
+    }
+
+    uint16_t *tbl  = (uint16_t *)smem;
+    uint32_t *ms   = (uint32_t *)(smem + L.off_ms);
+    uint32_t *vlcw = (uint32_t *)(smem + L.off_vlc);
+    uint8_t  *suf  = smem + L.off_suf;
+    uint32_t *qinfo = (uint32_t *)(smem + L.off_qinfo);
+    uint8_t  *Earr = smem + L.off_E;
+    uint32_t *bm   = (uint32_t *)(smem + L.off_bm);
+    const int Estride = 2 * (int)L.max_qw + 8;
+    const uint32_t nms = (Pcup * 8 + 31) / 32 + 2, nvl = (Scup * 8 + 31) / 32 + 2;
+
+    /* ---- stage 0: tables, zero, un-stuff ---- */
+    for (int i = lane; i < 1024; i += 64)
+        ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+    for (uint32_t i = lane; i < nms; i += 64) ms[i] = 0;
+    for (uint32_t i = lane; i < nvl; i += 64) vlcw[i] = 0;
+    for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
+    for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
+    if (z_blk > 1)
+        for (uint32_t i = lane; i < 4 * L.bm_words; i += 64) bm[i] = 0;
+    __syncthreads();
+
+    uint32_t ms_total;
+    {   /* MagSgn: forward, a byte after 0xFF advances 7 bits but ORs all 8 (jpeg2000htdec.c:207-221) */
+        uint32_t base = 0;
+        for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool act = i < Pcup;
+            const uint32_t byte = act ? D[i] : 0;
+            const uint32_t prev = (act && i > 0) ? D[i - 1] : 0;
+            const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(nb, lane);
+            const uint32_t off = base + incl - nb;
+            if (act) {
+                atomicOr(&ms[off >> 5], byte << (off & 31));
+                if ((off & 31) > 24) atomicOr(&ms[(off >> 5) + 1], byte >> (32 - (off & 31)));
+            }
+            base += __shfl(incl, 63, 64);
+        }
+        ms_total = base;
+    }
+    {   /* VLC: backward from Dcup[Lcup-2]; Dcup[Lcup-1] counts as 0xFF and the low nibble of
+         * Dcup[Lcup-2] as 0xF (:1277-1278); a byte with 7 LSBs set below a byte > 0x8F loses its MSB */
+        uint32_t base = 0;
+        const uint32_t nv = Scup - 1;                 /* bytes Lcup-2 .. Pcup */
+        for (uint32_t k0 = 0; k0 < nv; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const bool act = k < nv;
+            uint32_t v = 0, above = 0xFF;
+            if (act) {
+                const uint32_t j = Lcup - 2 - k;
+                v = D[j];
+                if (k == 0) v |= 0x0F;
+                else { above = D[j + 1]; if (k == 1) above |= 0x0F; }
+            }
+            const uint32_t nb = act ? ((above > 0x8F && (v & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            v &= (1u << nb) - 1;
+            const uint32_t incl = wave_incl_scan_u32(nb, lane);
+            const uint32_t off = base + incl - nb;
+            if (act) {
+                atomicOr(&vlcw[off >> 5], v << (off & 31));
+                if ((off & 31) > 24) atomicOr(&vlcw[(off >> 5) + 1], v >> (32 - (off & 31)));
+            }
+            base += __shfl(incl, 63, 64);
+        }
+    }
+    for (uint32_t i = lane; i < Scup; i += 64) {       /* MEL reads the (patched) suffix bytes */
+        uint32_t v = D[Pcup + i];
+        if (Pcup + i == Lcup - 1) v = 0xFF;
+        else if (Pcup + i == Lcup - 2) v |= 0x0F;
+        suf[i] = (uint8_t)v;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nms; i += 64) {        /* past the end the MagSgn stream is all ones */
+        if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
+        else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
+    }
+    __syncthreads();
+
+    HtSerial S;
+    S.vbuf = 0; S.vbits = 0; S.vword = 0; S.vlc = vlcw; S.vlc_words = nvl;
+    S.suf = suf; S.mel_pos = 0; S.mel_len = Scup; S.mel_tmp = 0; S.mel_bits = 0;
+    S.mel_k = 0; S.mel_run = 0; S.mel_one = 0;
+    if (lane == 0) S.vdrop(0), S.vfill(), S.vdrop(4);   /* jpeg2000_init_vlc drops the Scup nibble, :283-295 */
+
+    float fscale = b.f_step;
+    fscale /= (float)(1 << (31 - b.M_b));              /* jpeg2000dec.c:2104-2106 */
+    const int i_step = b.i_step, M_b = b.M_b, roi_shift = b.roi_shift;
+
+    uint32_t ms_pos = 0;                               /* bit position in the un-stuffed MagSgn stream */
+    int ctx_run = 0;                                   /* first-row context carried along the row */
+    const int bmW = w + 2;                             /* bitmap row pitch (1-cell border) */
+
+    for (int row = 0; row < qh && !err; row++) {
+        uint32_t *qcur = qinfo + (row & 1) * L.max_qw, *qprev = qinfo + ((row & 1) ^ 1) * L.max_qw;
+        uint8_t *Ecur = Earr + (row & 1) * Estride + 4, *Eprev = Earr + ((row & 1) ^ 1) * Estride + 4;
+
+        /* ---- stage 1: serial quad-row decode on lane 0 ---- */
+        if (lane == 0) {
+            const uint16_t *table = tbl + (row ? 1024 : 0);
+            int rho_left = 0;
+            for (int qx = 0; qx < qw; qx += 2) {
+                const int npair = (qx + 1 < qw) ? 2 : 1;
+                int rho[2] = { 0, 0 }, uoff[2] = { 0, 0 }, ek[2] = { 0, 0 }, e1[2] = { 0, 0 }, u[2] = { 0, 0 };
+                for (int k = 0; k < npair; k++) {
+                    const int q = qx + k;
+                    int ctx;
+                    if (row == 0) {
+                        ctx = ctx_run;
+                    } else {
+                        const int ra  = qprev[q] & 0xF;
+                        const int ral = q > 0 ? (qprev[q - 1] & 0xF) : 0;
+                        const int rar = q + 1 < qw ? (qprev[q + 1] & 0xF) : 0;
+                        const int rl  = q > 0 ? rho_left : 0;
+                        ctx = (((ra >> 1) | (ral >> 3)) & 1) | ((((rl >> 2) | (rl >> 3)) & 1) << 1) |
+                              ((((ra >> 3) | (rar >> 1)) & 1) << 2);
+                    }
+                    if (ctx != 0 || S.mel_sym() != 0) {
+                        const uint32_t e = table[(ctx << 7) | S.vpeek(7)];
+                        S.vdrop((e >> 1) & 7);
+                        uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; ek[k] = (e >> 8) & 0xF; e1[k] = (e >> 12) & 0xF;
+                    }
+                    rho_left = rho[k];
+                    if (row == 0)
+                        ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
+                }
+                if (npair == 2 && uoff[0] && uoff[1]) {
+                    if (row == 0) {
+                        if (S.mel_sym()) {
+                            const int p1 = S.upfx(), p2 = S.upfx();
+                            const int s1 = S.usfx(p1), s2 = S.usfx(p2);
+                            const int x1 = S.uext(s1), x2 = S.uext(s2);
+                            u[0] = 2 + p1 + s1 + 4 * x1;
+                            u[1] = 2 + p2 + s2 + 4 * x2;
+                        } else {
+                            const int p1 = S.upfx();
+                            if (p1 > 2) {
+                                u[1] = (int)S.vget(1) + 1;
+                                const int s1 = S.usfx(p1), x1 = S.uext(s1);
+                                u[0] = p1 + s1 + 4 * x1;
+                            } else {
+                                const int p2 = S.upfx();
+                                const int s1 = S.usfx(p1), s2 = S.usfx(p2);
+                                const int x1 = S.uext(s1), x2 = S.uext(s2);
+                                u[0] = p1 + s1 + 4 * x1;
+                                u[1] = p2 + s2 + 4 * x2;
+                            }
+                        }
+                    } else {
+                        const int p1 = S.upfx(), p2 = S.upfx();
+                        const int s1 = S.usfx(p1), s2 = S.usfx(p2);
+                        const int x1 = S.uext(s1), x2 = S.uext(s2);
+                        u[0] = p1 + s1 + 4 * x1;
+                        u[1] = p2 + s2 + 4 * x2;
+                    }
+                } else {
+                    for (int k = 0; k < npair; k++)
+                        if (uoff[k]) {
+                            const int p = S.upfx(), s = S.usfx(p), x = S.uext(s);
+                            u[k] = p + s + 4 * x;
+                        }
+                }
+                for (int k = 0; k < npair; k++)
+                    qcur[qx + k] = (uint32_t)rho[k] | ((uint32_t)ek[k] << 4) | ((uint32_t)e1[k] << 8) | ((uint32_t)u[k] << 16);
+            }
+        }
+        __syncthreads();
+
+        /* ---- stage 2: MagSgn of the quad row, lanes = sample columns ---- */
+        const int ncols = 2 * qw;
+        int row_err = 0;
+        for (int c0 = 0; c0 < ncols; c0 += 64) {
+            const int col = c0 + lane;
+            const bool act = col < ncols;
+            const int q = col >> 1;
+            const uint32_t qi = act ? qcur[q] : 0;
+            const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+            int kappa = 1;
+            if (row > 0 && act) {                      /* :855-885; Eprev[-1] and Eprev[ncols] are 0 */
+                const int x2 = 2 * q;
+                int me = max(max((int)Eprev[x2 - 1], (int)Eprev[x2]), max((int)Eprev[x2 + 1], (int)Eprev[x2 + 2]));
+                const int gamma = (rho & (rho - 1)) != 0;           /* more than one significant sample */
+                kappa = max(1, gamma * (me - 1));
+            }
+            const int U = kappa + uq;
+            if (act && U > maxbp) row_err = 1;         /* :715,756,889,961 */
+            const int sh = (col & 1) * 2;              /* samples 0,1 (left column) or 2,3 (right column) */
+            const int s_t = (rho >> sh) & 1, s_b = (rho >> (sh + 1)) & 1;
+            int m_t = act ? s_t * U - ((ekq >> sh) & 1) : 0;
+            int m_b = act ? s_b * U - ((ekq >> (sh + 1)) & 1) : 0;
+            /* a negative m (e_k outside rho: not in the Annex C tables) reads no bits */
+            const uint32_t nb = (uint32_t)(max(m_t, 0) + max(m_b, 0));
+            const uint32_t incl = wave_incl_scan_u32(nb, lane);
+            uint32_t pos = ms_pos + incl - nb;
+            uint32_t smag[2] = { 0, 0 };
+            int Ebot = 0;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int m = r ? m_b : m_t;
+                const int e1b = (e1q >> (sh + r)) & 1;
+                if (m != 0) {
+                    uint32_t v = 0;
+                    if (m > 0) {
+                        const uint32_t wi = min(pos >> 5, nms - 1), wj = min((pos >> 5) + 1, nms - 1);
+                        const uint64_t two = ((uint64_t)ms[wj] << 32) | ms[wi];
+                        v = (uint32_t)(two >> (pos & 31)) & (uint32_t)((1ull << m) - 1);
+                        v += (uint32_t)e1b << m;
+                        pos += m;
+                    }
+                    const int E = 32 - __clz((int)(v | 1));
+                    uint32_t mu = (v >> 1) + 1;
+                    mu <<= pLSB;
+                    mu |= 1u << ((pLSB - 1) & 31);
+                    mu |= (v & 1) << 31;
+                    smag[r] = mu;
+                    if (r) Ebot = E;
+                }
+            }
+            if (act) Ecur[col] = (uint8_t)Ebot;
+            ms_pos += __shfl(incl, 63, 64);
+
+            /* raster positions of this lane's two samples; odd sizes: the outside half of the
+             * border quads is discarded (:976-1007) */
+            const int y0 = 2 * row;
+            if (act && col < w) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int y = y0 + r;
+                    if (y >= h) continue;
+                    if (z_blk > 1) {
+                        dst[(size_t)y * stride + col] = smag[r];          /* raw, finished in stage 3 */
+                        if (((rho >> (sh + r)) & 1))
+                            atomicOr(&bm[((y + 1) * bmW + col + 1) >> 5], 1u << (((y + 1) * bmW + col + 1) & 31));
+                    } else {
+                        dst[(size_t)y * stride + col] = ht_dequant(smag[r], transform, M_b, roi_shift, fscale, i_step);
+                    }
+                }
+            }
+        }
+        if (__any(row_err)) err = HT_ERR_INVALID;
+        __syncthreads();
+    }
+
+    if (err) {
+        __syncthreads();
+        ht_zero_window(dst, w, h, stride, lane);
+        if (lane == 0) status[blockIdx.x] = err;
+        return;
+    }
+    if (z_blk <= 1) return;
+
+    /* ---- stage 3: refinement passes on bitmaps (bit index = (y+1)*(w+2) + x+1) ---- */
+    uint32_t *bm_sig = bm, *bm_ref = bm + L.bm_words, *bm_sgn = bm + 2 * L.bm_words, *bm_mr = bm + 3 * L.bm_words;
+    const uint8_t *Dref = D + Lcup;
+    const int causal = b.flags & J2K_CBLK_VSC;
+    __syncthreads();
+    if (lane == 0) {
+        /* SigProp, jpeg2000htdec.c:1016-1131: forward LSB-first reader, 7 bits after 0xFF, zeros past Lref */
+        uint32_t pos = 0, tmp = 0, last = 0; int bits = 0;
+        auto rdbit = [&]() -> int {
+            if (bits == 0) {
+                bits = (last == 0xFF) ? 7 : 8;
+                if (pos < Lref) { tmp = Dref[pos]; pos++; } else tmp = 0;
+                last = tmp;
+            }
+            int bit = tmp & 1; tmp >>= 1; bits--;
+            return bit;
+        };
+        for (int i0 = 0; i0 < h; i0 += 4) {
+            const int gh = min(4, h - i0);
+            for (int j0 = 0; j0 < w; j0 += 4) {
+                const int gw = min(4, w - j0);
+                for (int j = j0; j < j0 + gw; j++)
+                    for (int i = i0; i < i0 + gh; i++) {
+                        const int c = (i + 1) * bmW + (j + 1);
+                        if (bm_get(bm_sig, c)) continue;
+                        const int below_ok = !causal || (i != i0 + gh - 1);
+                        int mbr = bm_get(bm_sig, c - bmW - 1) | bm_get(bm_sig, c - bmW) | bm_get(bm_sig, c - bmW + 1) |
+                                  bm_get(bm_sig, c - 1) | bm_get(bm_sig, c + 1) |
+                                  bm_get(bm_ref, c - bmW - 1) | bm_get(bm_ref, c - bmW) | bm_get(bm_ref, c - bmW + 1) |
+                                  bm_get(bm_ref, c - 1) | bm_get(bm_ref, c + 1);
+                        if (below_ok)
+                            mbr |= bm_get(bm_sig, c + bmW - 1) | bm_get(bm_sig, c + bmW) | bm_get(bm_sig, c + bmW + 1) |
+                                   bm_get(bm_ref, c + bmW - 1) | bm_get(bm_ref, c + bmW) | bm_get(bm_ref, c + bmW + 1);
+                        if (mbr && rdbit())
+                            bm_ref[c >> 5] |= 1u << (c & 31);
+                    }
+                for (int j = j0; j < j0 + gw; j++)
+                    for (int i = i0; i < i0 + gh; i++) {
+                        const int c = (i + 1) * bmW + (j + 1);
+                        if (bm_get(bm_ref, c) && rdbit())
+                            bm_sgn[c >> 5] |= 1u << (c & 31);
+                    }
+            }
+        }
+        if (z_blk > 2) {
+            /* MagRef, :1137-1185: backward reader over Dref with the VLC un-stuffing rule; the byte
+             * after the segment counts as 0xFF (:1260), bytes below Dref[0] read as zero bits */
+            int rpos = (int)Lref - 1; uint32_t above = 0xFF, cur = 0; int nb = 0;
+            auto rdback = [&]() -> int {
+                if (nb == 0) {
+                    if (rpos >= 0) {
+                        cur = Dref[rpos];
+                        nb = (above > 0x8F && (cur & 0x7F) == 0x7F) ? 7 : 8;
+                        above = cur;
+                        rpos--;
+                    } else { cur = 0; nb = 8; }
+                }
+                int bit = cur & 1; cur >>= 1; nb--;
+                return bit;
+            };
+            for (int i0 = 0; i0 < h; i0 += 4)
+                for (int j = 0; j < w; j++)
+                    for (int i = i0; i < min(i0 + 4, h); i++) {
+                        const int c = (i + 1) * bmW + (j + 1);
+                        if (bm_get(bm_sig, c) && rdback())
+                            bm_mr[c >> 5] |= 1u << (c & 31);
+                    }
+        }
+    }
+    __syncthreads();
+    {
+        const int qq = (pLSB - 1) & 31;                /* both passes are called with pLSB - 1, :1309-1315 */
+        for (int y = 0; y < h; y++)
+            for (int x = lane; x < w; x += 64) {
+                const int c = (y + 1) * bmW + (x + 1);
+                uint32_t v = dst[(size_t)y * stride + x];
+                if (bm_get(bm_ref, c)) {
+                    v |= 1u << qq;
+                    v |= 1u << ((qq - 1) & 31);
+                    v |= (uint32_t)bm_get(bm_sgn, c) << 31;
+                }
+                if (z_blk > 2 && bm_get(bm_sig, c)) {
+                    v &= (0xFFFFFFFEu | (uint32_t)bm_get(bm_mr, c)) << qq;
+                    v |= 1u << ((qq - 1) & 31);
+                }
+                dst[(size_t)y * stride + x] = ht_dequant(v, transform, M_b, roi_shift, fscale, i_step);
+            }
+    }
+}
+
+}  // namespace htj2k

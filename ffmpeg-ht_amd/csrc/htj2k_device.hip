@@ -1,0 +1,893 @@
+/*
+ * htj2k_device.hip -- the C ABI of include/htj2k_amd.h: device management, the frame
+ * pipeline (parse -> H2D -> HT decode -> IDWT -> MCT/pack -> D2H) and the kernel launches.
+ *
+ * Mirrors the plugin surface of `ff_jpeg2000_decoder` (libavcodec/jpeg2000dec.c:2926-2939):
+ * htj2k_open = FFCodec.init, htj2k_decode = FFCodec.cb.decode (jpeg2000_decode_frame,
+ * :2825-2908), htj2k_close = FFCodec.close.  There is no CPU fallback anywhere in this
+ * library: without a usable HIP device htj2k_open fails with HTJ2K_ERR_ENOSYS.
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <vector>
+
+#include "../../include/htj2k_amd.h"
+#include "j2k_plan.h"
+#include "ht_cxtvlc_rows.h"
+#include "ht_kernels.hpp"
+#include "dwt_kernels.hpp"
+#include "pack_kernels.hpp"
+
+using namespace htj2k;
+
+#define LOG_ERROR 16
+#define LOG_WARNING 24
+#define LOG_INFO 32
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return HTJ2K_ERR_ENOMEM; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct htj2k_ctx {
+    htj2k_opts opts;
+    int device = 0;
+    char devname[256];
+    htj2k_log_fn log = nullptr;
+    void *log_opaque = nullptr;
+    uint16_t *d_tables = nullptr;      /* 2 x 1024 CxtVLC decode entries */
+    J2kParser *probe_parser = nullptr;
+    htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
+    int idwt_mode = 1;                 /* 0 = generic two-pass kernels, 1 = fused LDS tile kernels */
+    int max_dyn_lds = 64 * 1024;
+};
+
+struct LevelLaunch {                   /* one IDWT launch: all planes of one type that have this level */
+    int type, level;
+    int count;                         /* planes */
+    size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_tables */
+    int max_lh, max_lv;
+};
+
+struct htj2k_job {
+    J2kParser *parser = nullptr;
+    const J2kPlan *plan = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_out[4];
+    std::vector<uint8_t> h_desc;       /* host image of d_desc: level tables + pack tiles */
+    std::vector<LevelLaunch> launches_generic, launches_tile;
+    size_t pack_off = 0; int npack = 0; int pack_maxw = 0, pack_maxh = 0;
+    size_t pack_off_generic = 0;
+    OutPlanes out;
+    HtLds lds;
+    int uploaded = 0, ran = 0;
+    float ms_ht = 0, ms_idwt = 0, ms_pack = 0;
+    int n_block_errors = 0;
+    std::vector<int> final_buf;        /* per tilecomp, tile mode: 0 = coef, 1 = t0, 2 = t1 */
+    std::vector<int> final_eff;        /* where each plane actually is after the last IDWT run */
+    bool tile_ok = true;               /* no empty levels: all planes of a launch ping-pong in step */
+};
+
+static void clog(htj2k_ctx *c, int level, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    if (!c || !c->log) return;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    c->log(c->log_opaque, level, buf);
+}
+
+static void parser_log_tramp(void *opaque, int level, const char *msg)
+{
+    htj2k_ctx *c = (htj2k_ctx *)opaque;
+    if (c && c->log) c->log(c->log_opaque, level, msg);
+}
+
+#define HIP_TRY(c, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            clog(c, LOG_ERROR, "HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+            return e_ == hipErrorOutOfMemory ? HTJ2K_ERR_ENOMEM : HTJ2K_ERR_EXTERNAL;         \
+        }                                                                                     \
+    } while (0)
+
+/* ------------------------------------------------------------------ CxtVLC decode tables
+ * expanded on the host from the Annex C rows (the reference's dec_cxt_vlc_table0/1,
+ * libavcodec/jpeg2000htdec.c:1342-1502, hold the same constants pre-expanded);
+ * entry: bit0 u_off, bits1-3 len, 4-7 rho, 8-11 e_k, 12-15 e_1 (:320-327) */
+static uint16_t h_tables[2][1024];
+static void tbl_row(int t, int ctx, int rho, int uoff, int ek, int e1, int cwd, int len)
+{
+    uint16_t v = (uint16_t)(uoff | (len << 1) | (rho << 4) | (ek << 8) | (e1 << 12));
+    for (int hi = 0; hi < (1 << (7 - len)); hi++)
+        h_tables[t][(ctx << 7) | (hi << len) | cwd] = v;
+}
+#define DROW0(c, r, u, k, o, w, l) tbl_row(0, c, r, u, k, o, w, l);
+#define DROW1(c, r, u, k, o, w, l) tbl_row(1, c, r, u, k, o, w, l);
+static void build_tables()
+{
+    HT_CXTVLC_ROWS0(DROW0)
+    HT_CXTVLC_ROWS1(DROW1)
+}
+
+/* ------------------------------------------------------------------ open / close */
+extern "C" const char *htj2k_version(void) { return "htj2k-amd 0.1 (gfx950)"; }
+
+extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
+{
+    int ndev = 0;
+    if (!out) return HTJ2K_ERR_EINVAL;
+    *out = nullptr;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return HTJ2K_ERR_ENOSYS;                 /* no GPU: fail loudly, there is no CPU path */
+    htj2k_ctx *c = new (std::nothrow) htj2k_ctx();
+    if (!c) return HTJ2K_ERR_ENOMEM;
+    memset(&c->opts, 0, sizeof(c->opts));
+    c->opts.req_pix_fmt = HTJ2K_PIX_NONE;
+    if (opts) c->opts = *opts;
+    c->device = c->opts.device_id;
+    if (c->device < 0 || c->device >= ndev) { delete c; return HTJ2K_ERR_EINVAL; }
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return HTJ2K_ERR_ENOSYS; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return HTJ2K_ERR_ENOSYS; }
+    snprintf(c->devname, sizeof(c->devname), "%s", prop.gcnArchName);
+    c->max_dyn_lds = (int)prop.sharedMemPerBlock;
+    build_tables();
+    if (hipMalloc((void **)&c->d_tables, sizeof(h_tables)) != hipSuccess ||
+        hipMemcpy(c->d_tables, h_tables, sizeof(h_tables), hipMemcpyHostToDevice) != hipSuccess) {
+        delete c;
+        return HTJ2K_ERR_ENOSYS;
+    }
+    c->probe_parser = j2k_parser_new();
+    if (!c->probe_parser) { (void)hipFree(c->d_tables); delete c; return HTJ2K_ERR_ENOMEM; }
+    const char *m = getenv("HTJ2K_IDWT");
+    if (m && !strcmp(m, "generic")) c->idwt_mode = 0;
+    if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
+    *out = c;
+    return 0;
+}
+
+extern "C" void htj2k_set_log(htj2k_ctx *c, htj2k_log_fn fn, void *opaque)
+{
+    if (!c) return;
+    c->log = fn;
+    c->log_opaque = opaque;
+    j2k_parser_set_log(c->probe_parser, fn ? parser_log_tramp : nullptr, c);
+}
+
+extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return HTJ2K_ERR_EINVAL;
+    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
+    if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
+    return HTJ2K_ERR_EINVAL;
+}
+
+extern "C" const char *htj2k_device_name(htj2k_ctx *c) { return c ? c->devname : ""; }
+
+extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
+{
+    (void)c;
+    if (!j) return;
+    if (j->stream) (void)hipStreamSynchronize(j->stream);
+    j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
+    j->d_t0.release(); j->d_t1.release(); j->d_desc.release();
+    for (int i = 0; i < 4; i++) j->d_out[i].release();
+    for (int i = 0; i < 6; i++) if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
+    if (j->stream) (void)hipStreamDestroy(j->stream);
+    j2k_parser_free(j->parser);
+    delete j;
+}
+
+extern "C" void htj2k_close(htj2k_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_job) htj2k_job_free(c, c->own_job);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    j2k_parser_free(c->probe_parser);
+    delete c;
+}
+
+extern "C" int htj2k_probe(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_info *info)
+{
+    const J2kPlan *pl = nullptr;
+    if (!c || !pkt || !info) return HTJ2K_ERR_EINVAL;
+    int ret = j2k_parse(c->probe_parser, pkt, size, &c->opts, 1, &pl);
+    if (ret < 0) return ret;
+    *info = pl->info;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ job: parse */
+static int job_new(htj2k_ctx *c, htj2k_job **out)
+{
+    htj2k_job *j = new (std::nothrow) htj2k_job();
+    if (!j) return HTJ2K_ERR_ENOMEM;
+    j->parser = j2k_parser_new();
+    if (!j->parser) { delete j; return HTJ2K_ERR_ENOMEM; }
+    j2k_parser_set_log(j->parser, parser_log_tramp, c);
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) {
+        j2k_parser_free(j->parser); delete j; return HTJ2K_ERR_EXTERNAL;
+    }
+    for (int i = 0; i < 6; i++)
+        if (hipEventCreate(&j->ev[i]) != hipSuccess) { htj2k_job_free(c, j); return HTJ2K_ERR_EXTERNAL; }
+    *out = j;
+    return 0;
+}
+
+extern "C" int htj2k_job_parse(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_job **job)
+{
+    if (!c || !pkt || !job) return HTJ2K_ERR_EINVAL;
+    if (!*job) {
+        int r = job_new(c, job);
+        if (r < 0) return r;
+    }
+    htj2k_job *j = *job;
+    /* the previous frame of this job may still be in flight and reads the parser's arena */
+    if (hipStreamSynchronize(j->stream) != hipSuccess) return HTJ2K_ERR_EXTERNAL;
+    j->uploaded = j->ran = 0;
+    j->plan = nullptr;
+    return j2k_parse(j->parser, pkt, size, &c->opts, 0, &j->plan);
+}
+
+extern "C" int htj2k_job_info(const htj2k_job *j, htj2k_info *info)
+{
+    if (!j || !j->plan || !info) return HTJ2K_ERR_EINVAL;
+    *info = j->plan->info;
+    return 0;
+}
+extern "C" int htj2k_job_bytes_consumed(const htj2k_job *j) { return j && j->plan ? j->plan->bytes_consumed : HTJ2K_ERR_EINVAL; }
+extern "C" int htj2k_job_num_tilecomps(const htj2k_job *j) { return j && j->plan ? j->plan->ntilecomps : HTJ2K_ERR_EINVAL; }
+extern "C" int htj2k_job_num_blocks(const htj2k_job *j) { return j && j->plan ? j->plan->nblocks : HTJ2K_ERR_EINVAL; }
+extern "C" int htj2k_job_tilecomp_dims(const htj2k_job *j, int tc, int *w, int *h, int *is_float)
+{
+    if (!j || !j->plan || tc < 0 || tc >= j->plan->ntilecomps) return HTJ2K_ERR_EINVAL;
+    if (w) *w = j->plan->tilecomps[tc].w;
+    if (h) *h = j->plan->tilecomps[tc].h;
+    if (is_float) *is_float = j->plan->tilecomps[tc].transform == J2K_DWT97;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ job: upload */
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int build_ht_lds(htj2k_ctx *c, htj2k_job *j)
+{
+    const J2kPlan *pl = j->plan;
+    uint32_t max_p = 0, max_s = 2, max_qw = 1, bm_words = 0;
+    for (int i = 0; i < pl->nblocks; i++) {
+        const J2kBlock &b = pl->blocks[i];
+        if (!b.npasses) continue;
+        uint32_t qw = (b.w + 1u) >> 1;
+        if (qw > max_qw) max_qw = qw;
+        if (b.lcup >= 2) {
+            const uint8_t *D = pl->bytes + b.data_off;
+            uint32_t scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
+            if (scup >= 2 && scup <= b.lcup && scup <= 4079) {
+                if (scup > max_s) max_s = scup;
+                if (b.lcup - scup > max_p) max_p = b.lcup - scup;
+            }
+        }
+        int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+        if (b.npasses - plhd > 1) {
+            uint32_t wds = ((uint32_t)(b.w + 2) * (b.h + 2) + 31) / 32 + 1;
+            if (wds > bm_words) bm_words = wds;
+        }
+    }
+    HtLds &L = j->lds;
+    size_t off = 4096;                                   /* the two CxtVLC tables */
+    L.ms_words = (max_p * 8 + 31) / 32 + 2;
+    L.off_ms = (uint32_t)off;  off += (size_t)L.ms_words * 4;
+    L.vlc_words = (max_s * 8 + 31) / 32 + 2;
+    L.off_vlc = (uint32_t)off; off += (size_t)L.vlc_words * 4;
+    L.suf_bytes = (uint32_t)align_up(max_s, 4);
+    L.off_suf = (uint32_t)off; off += L.suf_bytes;
+    L.max_qw = max_qw;
+    L.off_qinfo = (uint32_t)off; off += (size_t)2 * max_qw * 4;
+    L.off_E = (uint32_t)off;   off += align_up((size_t)2 * (2 * max_qw + 8), 4);
+    L.bm_words = bm_words;
+    L.off_bm = (uint32_t)off;  off += (size_t)4 * bm_words * 4;
+    L.total = (uint32_t)align_up(off, 16);
+    if ((int)L.total > 160 * 1024) {
+        clog(c, LOG_ERROR, "a codeblock needs %u bytes of LDS\n", L.total);
+        return HTJ2K_ERR_PATCHWELCOME;
+    }
+    return 0;
+}
+
+static void push_bytes(std::vector<uint8_t> &v, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    v.insert(v.end(), b, b + n);
+}
+
+/* descriptor tables for the IDWT launches and the pack stage */
+static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
+{
+    const J2kPlan *pl = j->plan;
+    j->h_desc.clear();
+    j->launches_generic.clear();
+    j->launches_tile.clear();
+    j->final_buf.assign(pl->ntilecomps, 0);
+    int maxlev = 0;
+    for (int t = 0; t < pl->ntilecomps; t++)
+        if (pl->tilecomps[t].coded && pl->tilecomps[t].ndeclevels > maxlev) maxlev = pl->tilecomps[t].ndeclevels;
+    for (int lev = 0; lev < maxlev; lev++)
+        for (int type = 0; type < 3; type++) {
+            LevelLaunch g, tl;
+            g.type = tl.type = type; g.level = tl.level = lev; g.count = tl.count = 0;
+            g.max_lh = g.max_lv = tl.max_lh = tl.max_lv = 0;
+            std::vector<DwtLevel> lv;
+            std::vector<DwtTileArgs> ta;
+            for (int t = 0; t < pl->ntilecomps; t++) {
+                const J2kTileComp &tc = pl->tilecomps[t];
+                if (!tc.coded || tc.transform != type || lev >= tc.ndeclevels) continue;
+                if (tc.linelen[lev][0] <= 0 || tc.linelen[lev][1] <= 0) continue;   /* empty level: no-op */
+                DwtLevel d;
+                d.plane_off = tc.plane_off; d.stride = tc.w;
+                d.lh = tc.linelen[lev][0]; d.lv = tc.linelen[lev][1];
+                d.mh = tc.mod[lev][0]; d.mv = tc.mod[lev][1];
+                d.last = (type == J2K_DWT97_INT && lev == tc.ndeclevels - 1) ? 1 : 0;
+                lv.push_back(d);
+                DwtTileArgs a;
+                a.g = d;
+                a.ll_off = tc.plane_off; a.ll_stride = tc.w;
+                a.out_off = tc.plane_off; a.out_stride = tc.w;
+                ta.push_back(a);
+                if (d.lh > g.max_lh) g.max_lh = d.lh;
+                if (d.lv > g.max_lv) g.max_lv = d.lv;
+            }
+            if (lv.empty()) continue;
+            g.count = tl.count = (int)lv.size();
+            tl.max_lh = g.max_lh; tl.max_lv = g.max_lv;
+            g.table_off = j->h_desc.size();
+            push_bytes(j->h_desc, lv.data(), lv.size() * sizeof(DwtLevel));
+            while (j->h_desc.size() % 16) j->h_desc.push_back(0);
+            tl.table_off = j->h_desc.size();
+            push_bytes(j->h_desc, ta.data(), ta.size() * sizeof(DwtTileArgs));
+            while (j->h_desc.size() % 16) j->h_desc.push_back(0);
+            j->launches_generic.push_back(g);
+            j->launches_tile.push_back(tl);
+        }
+    /* tile mode ping-pongs between the two scratch buffers: the level that actually runs
+     * k-th for a plane reads LL from buffer (k-1) and writes buffer k (1 = t0, 2 = t1) */
+    j->tile_ok = true;
+    for (int t = 0; t < pl->ntilecomps; t++) {
+        const J2kTileComp &tc = pl->tilecomps[t];
+        int k = 0;
+        if (tc.coded)
+            for (int lev = 0; lev < tc.ndeclevels; lev++) {
+                if (tc.linelen[lev][0] > 0 && tc.linelen[lev][1] > 0) k++;
+                else j->tile_ok = false;       /* a level deeper than the size allows: planes would fall out of step */
+            }
+        j->final_buf[t] = k == 0 ? 0 : 1 + ((k - 1) & 1);
+    }
+    j->final_eff.assign(pl->ntilecomps, 0);
+    /* pack tiles: two variants of the source pointers (generic mode ends in coef) are
+     * patched at launch time, so only geometry is stored here */
+    j->pack_off = j->h_desc.size();
+    j->npack = pl->ntiles;
+    j->pack_maxw = j->pack_maxh = 0;
+    for (int ti = 0; ti < pl->ntiles; ti++) {
+        PackTile T;
+        memset(&T, 0, sizeof(T));
+        T.ncomp = pl->info.ncomponents;
+        T.out_bytes = pl->out_bytes;
+        T.precision = pl->out_shift_precision;
+        for (int cc = 0; cc < T.ncomp; cc++) {
+            const J2kTileComp &tc = pl->tilecomps[ti * T.ncomp + cc];
+            PackComp &C = T.c[cc];
+            C.src = nullptr;
+            C.w = tc.w; C.h = tc.h; C.transform = tc.transform; C.cbps = tc.cbps;
+            C.out_plane = tc.out_plane; C.out_x = tc.out_x; C.out_y = tc.out_y;
+            C.pix_step = tc.pix_step; C.pix_off = tc.pix_off;
+            if (tc.w > T.maxw) T.maxw = tc.w;
+            if (tc.h > T.maxh) T.maxh = tc.h;
+            if (cc == 0) T.mct = tc.mct;
+        }
+        if (T.maxw > j->pack_maxw) j->pack_maxw = T.maxw;
+        if (T.maxh > j->pack_maxh) j->pack_maxh = T.maxh;
+        push_bytes(j->h_desc, &T, sizeof(T));
+    }
+    (void)c;
+    return 0;
+}
+
+extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
+{
+    if (!c || !j || !j->plan) return HTJ2K_ERR_EINVAL;
+    const J2kPlan *pl = j->plan;
+    int r;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((r = build_ht_lds(c, j)) < 0) return r;
+    if ((r = build_descriptors(c, j)) < 0) return r;
+    const size_t coef_bytes = (pl->nsamples + 64) * sizeof(uint32_t);
+    if ((r = j->d_bytes.ensure(pl->nbytes + 64)) < 0) return r;
+    if ((r = j->d_blocks.ensure((size_t)(pl->nblocks + 1) * sizeof(J2kBlock))) < 0) return r;
+    if ((r = j->d_status.ensure((size_t)(pl->nblocks + 1) * sizeof(int))) < 0) return r;
+    if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
+    if ((r = j->d_t0.ensure(coef_bytes)) < 0) return r;
+    if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
+    if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
+    memset(&j->out, 0, sizeof(j->out));
+    for (int p = 0; p < pl->info.nplanes; p++) {
+        const int ls = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
+        if ((r = j->d_out[p].ensure((size_t)ls * pl->info.plane_height[p] + 64)) < 0) return r;
+        j->out.ptr[p] = (uint8_t *)j->d_out[p].p;
+        j->out.linesize[p] = ls;
+        j->out.width[p] = pl->info.plane_width[p];
+        j->out.height[p] = pl->info.plane_height[p];
+    }
+    HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
+    if (pl->nbytes)
+        HIP_TRY(c, hipMemcpyAsync(j->d_bytes.p, pl->bytes, pl->nbytes, hipMemcpyHostToDevice, j->stream));
+    if (pl->nblocks)
+        HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, pl->blocks, (size_t)pl->nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
+    HIP_TRY(c, hipEventRecord(j->ev[1], j->stream));
+    j->uploaded = 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ job: run */
+static uint32_t *buf_ptr(htj2k_job *j, int which)
+{
+    return (uint32_t *)(which == 0 ? j->d_coef.p : which == 1 ? j->d_t0.p : j->d_t1.p);
+}
+
+template <int TYPE>
+static void launch_generic_level(htj2k_job *j, const LevelLaunch &L)
+{
+    const DwtLevel *tab = (const DwtLevel *)((uint8_t *)j->d_desc.p + L.table_off);
+    dim3 gh((L.max_lh + 255) / 256, L.max_lv, L.count), gv((L.max_lh + 255) / 256, L.max_lv, L.count);
+    hipLaunchKernelGGL((k_idwt_h<TYPE>), gh, dim3(256), 0, j->stream, tab, (const uint32_t *)j->d_coef.p, (uint32_t *)j->d_t0.p);
+    hipLaunchKernelGGL((k_idwt_v<TYPE>), gv, dim3(256), 0, j->stream, tab, (const uint32_t *)j->d_t0.p, (uint32_t *)j->d_coef.p);
+}
+
+#define TILE_W 64
+#define TILE_H 32
+
+template <int TYPE>
+static void launch_tile_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
+{
+    const DwtTileArgs *tab = (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off);
+    dim3 g((L.max_lh + TILE_W - 1) / TILE_W, (L.max_lv + TILE_H - 1) / TILE_H, L.count);
+    hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, j->stream, tab, ll,
+                       (const uint32_t *)j->d_coef.p, out);
+}
+
+static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile)
+{
+    (void)c;
+    if (!use_tile) {
+        for (const LevelLaunch &L : j->launches_generic) {
+            if (L.type == J2K_DWT53) launch_generic_level<J2K_DWT53>(j, L);
+            else if (L.type == J2K_DWT97) launch_generic_level<J2K_DWT97>(j, L);
+            else launch_generic_level<J2K_DWT97_INT>(j, L);
+        }
+        return 0;
+    }
+    for (const LevelLaunch &L : j->launches_tile) {
+        const uint32_t *ll = buf_ptr(j, L.level == 0 ? 0 : 1 + ((L.level - 1) & 1));
+        uint32_t *out = buf_ptr(j, 1 + (L.level & 1));
+        if (L.type == J2K_DWT53) launch_tile_level<J2K_DWT53>(j, L, ll, out);
+        else if (L.type == J2K_DWT97) launch_tile_level<J2K_DWT97>(j, L, ll, out);
+        else launch_tile_level<J2K_DWT97_INT>(j, L, ll, out);
+    }
+    return 0;
+}
+
+extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
+{
+    if (!c || !j || !j->plan || !j->uploaded) return HTJ2K_ERR_EINVAL;
+    const J2kPlan *pl = j->plan;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (mask & 1) {
+        HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
+        if (pl->nblocks) {
+            HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)pl->nblocks * sizeof(int), j->stream));
+            if ((int)j->lds.total > 48 * 1024)
+                HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
+            hipLaunchKernelGGL(k_ht_decode, dim3(pl->nblocks), dim3(64), j->lds.total, j->stream,
+                               (const J2kBlock *)j->d_blocks.p, pl->nblocks, (const uint8_t *)j->d_bytes.p,
+                               (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
+    }
+    if (mask & 6) {
+        const bool use_tile = c->idwt_mode != 0 && j->tile_ok;
+        if (mask & 2)
+            for (int t = 0; t < pl->ntilecomps; t++) j->final_eff[t] = use_tile ? j->final_buf[t] : 0;
+        /* one upload of all descriptor tables, pack source pointers patched for where the
+         * planes are (or will be) after the IDWT */
+        PackTile *T = (PackTile *)(j->h_desc.data() + j->pack_off);
+        for (int ti = 0; ti < pl->ntiles; ti++)
+            for (int cc = 0; cc < T[ti].ncomp; cc++) {
+                const int t = ti * T[ti].ncomp + cc;
+                T[ti].c[cc].src = buf_ptr(j, j->final_eff[t]) + pl->tilecomps[t].plane_off;
+            }
+        if (!(mask & 1)) HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
+        HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
+        if (mask & 2) {
+            int r = run_idwt(c, j, use_tile);
+            if (r < 0) return r;
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(j->ev[4], j->stream));
+    }
+    if (mask & 4) {
+        if (j->npack && j->pack_maxw > 0 && j->pack_maxh > 0) {
+            dim3 g((j->pack_maxw + 255) / 256, j->pack_maxh, j->npack);
+            hipLaunchKernelGGL(k_mct_pack, g, dim3(256), 0, j->stream,
+                               (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off), j->out);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(j->ev[5], j->stream));
+    }
+    j->ran |= mask;
+    return 0;
+}
+
+extern "C" int htj2k_job_run(htj2k_ctx *c, htj2k_job *j) { return htj2k_job_run_stages(c, j, 7); }
+
+extern "C" int htj2k_job_wait(htj2k_ctx *c, htj2k_job *j)
+{
+    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    return 0;
+}
+
+extern "C" int htj2k_job_stage_ms(htj2k_ctx *c, htj2k_job *j, float *ms_ht, float *ms_idwt, float *ms_pack)
+{
+    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    float a = 0, b = 0, d = 0;
+    if (j->ran & 1) (void)hipEventElapsedTime(&a, j->ev[2], j->ev[3]);
+    if (j->ran & 2) (void)hipEventElapsedTime(&b, j->ev[3], j->ev[4]);
+    if (j->ran & 4) (void)hipEventElapsedTime(&d, j->ev[4], j->ev[5]);
+    if (ms_ht) *ms_ht = a;
+    if (ms_idwt) *ms_idwt = b;
+    if (ms_pack) *ms_pack = d;
+    return 0;
+}
+
+extern "C" int htj2k_job_block_errors(htj2k_ctx *c, htj2k_job *j)
+{
+    if (!c || !j || !j->plan) return HTJ2K_ERR_EINVAL;
+    const int n = j->plan->nblocks;
+    if (!n) return 0;
+    std::vector<int> st(n);
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    HIP_TRY(c, hipMemcpy(st.data(), j->d_status.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    int e = 0;
+    for (int i = 0; i < n; i++) e += st[i] != 0;
+    return e;
+}
+
+extern "C" int htj2k_job_read_plane(htj2k_ctx *c, htj2k_job *j, int tc, void *dst, size_t dst_bytes)
+{
+    if (!c || !j || !j->plan || tc < 0 || tc >= j->plan->ntilecomps) return HTJ2K_ERR_EINVAL;
+    const J2kTileComp &t = j->plan->tilecomps[tc];
+    const size_t n = (size_t)t.w * t.h * 4;
+    if (dst_bytes < n) return HTJ2K_ERR_EINVAL;
+    const int fb = j->final_eff.empty() ? 0 : j->final_eff[tc];
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    HIP_TRY(c, hipMemcpy(dst, buf_ptr(j, fb) + t.plane_off, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame)
+{
+    if (!c || !j || !j->plan || !frame) return HTJ2K_ERR_EINVAL;
+    const J2kPlan *pl = j->plan;
+    for (int p = 0; p < pl->info.nplanes; p++) {
+        const int rowbytes = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
+        if (!frame->data[p] || frame->linesize[p] < rowbytes) return HTJ2K_ERR_EINVAL;
+        HIP_TRY(c, hipMemcpy2DAsync(frame->data[p], frame->linesize[p], j->d_out[p].p, j->out.linesize[p],
+                                    rowbytes, pl->info.plane_height[p], hipMemcpyDeviceToHost, j->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    frame->width = pl->info.width;
+    frame->height = pl->info.height;
+    frame->pix_fmt = pl->info.pix_fmt;
+    return 0;
+}
+
+/* device address of an output plane (for callers that keep frames on the GPU) */
+extern "C" void *htj2k_job_device_plane(htj2k_job *j, int plane, int *linesize)
+{
+    if (!j || plane < 0 || plane > 3) return nullptr;
+    if (linesize) *linesize = j->out.linesize[plane];
+    return j->out.ptr[plane];
+}
+
+/* ------------------------------------------------------------------ one-call decode */
+extern "C" int htj2k_decode(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_frame *frame, htj2k_stats *stats)
+{
+    if (!c || !pkt || !frame) return HTJ2K_ERR_EINVAL;
+    auto t0 = std::chrono::steady_clock::now();
+    int r = htj2k_job_parse(c, pkt, size, &c->own_job);
+    if (r < 0) return r;
+    auto t1 = std::chrono::steady_clock::now();
+    htj2k_job *j = c->own_job;
+    if ((r = htj2k_job_upload(c, j)) < 0) return r;
+    if ((r = htj2k_job_run(c, j)) < 0) return r;
+    auto t2 = std::chrono::steady_clock::now();
+    if ((r = htj2k_job_download(c, j, frame)) < 0) return r;
+    auto t3 = std::chrono::steady_clock::now();
+    int nerr = htj2k_job_block_errors(c, j);
+    if (nerr > 0)
+        clog(c, LOG_ERROR, "Bad HT cleanup segment in %d codeblock(s)\n", nerr);   /* jpeg2000htdec.c:1305 */
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->n_codeblocks = j->plan->nblocks;
+        stats->n_block_errors = nerr > 0 ? nerr : 0;
+        stats->ms_parse = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        (void)hipEventElapsedTime(&stats->ms_h2d, j->ev[0], j->ev[1]);
+        (void)hipEventElapsedTime(&stats->ms_kernels, j->ev[2], j->ev[5]);
+        stats->ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
+        htj2k_job_stage_ms(c, j, &stats->ms_ht, &stats->ms_idwt, &stats->ms_pack);
+    }
+    return j->plan->bytes_consumed;
+}
+
+/* ------------------------------------------------------------------ kernel-level entry points */
+static void fill_levels(const int border[2][2], int levels, int32_t linelen[][2], uint8_t mod[][2])
+{
+    int b[2][2], lev = levels;
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 2; k++) b[i][k] = border[i][k];
+    while (--lev >= 0)
+        for (int i = 0; i < 2; i++) {
+            linelen[lev][i] = b[i][1] - b[i][0];
+            mod[lev][i] = b[i][0] & 1;
+            for (int k = 0; k < 2; k++) b[i][k] = (b[i][k] + 1) >> 1;
+        }
+}
+
+struct PlaneSet {                 /* nplanes identical-geometry planes laid out back to back */
+    int w, h, levels, type, nplanes;
+    size_t plane_samples;
+    std::vector<std::vector<uint8_t>> tables_generic, tables_tile;   /* per level */
+    std::vector<int> lh, lv;
+};
+
+static void planeset_build(PlaneSet &P, const int border[2][2], int levels, int type, int nplanes)
+{
+    int32_t linelen[J2K_MAX_DWTLEV][2]; uint8_t mod[J2K_MAX_DWTLEV][2];
+    P.w = border[0][1] - border[0][0]; P.h = border[1][1] - border[1][0];
+    P.levels = levels; P.type = type; P.nplanes = nplanes;
+    P.plane_samples = align_up((size_t)P.w * P.h, 64);
+    fill_levels(border, levels, linelen, mod);
+    for (int lev = 0; lev < levels; lev++) {
+        std::vector<uint8_t> tg, tt;
+        for (int p = 0; p < nplanes; p++) {
+            DwtLevel d;
+            d.plane_off = (uint32_t)(p * P.plane_samples); d.stride = P.w;
+            d.lh = linelen[lev][0]; d.lv = linelen[lev][1]; d.mh = mod[lev][0]; d.mv = mod[lev][1];
+            d.last = (type == J2K_DWT97_INT && lev == levels - 1);
+            DwtTileArgs a; a.g = d; a.ll_off = d.plane_off; a.ll_stride = P.w; a.out_off = d.plane_off; a.out_stride = P.w;
+            push_bytes(tg, &d, sizeof(d));
+            push_bytes(tt, &a, sizeof(a));
+        }
+        P.tables_generic.push_back(tg); P.tables_tile.push_back(tt);
+        P.lh.push_back(linelen[lev][0]); P.lv.push_back(linelen[lev][1]);
+    }
+}
+
+template <int TYPE>
+static void planeset_launch_level(const PlaneSet &P, int lev, int mode, int kth, const void *d_tab,
+                                  uint32_t *coef, uint32_t *t0, uint32_t *t1, hipStream_t s)
+{
+    if (mode == 0) {
+        dim3 g((P.lh[lev] + 255) / 256, P.lv[lev], P.nplanes);
+        hipLaunchKernelGGL((k_idwt_h<TYPE>), g, dim3(256), 0, s, (const DwtLevel *)d_tab, (const uint32_t *)coef, t0);
+        hipLaunchKernelGGL((k_idwt_v<TYPE>), g, dim3(256), 0, s, (const DwtLevel *)d_tab, (const uint32_t *)t0, coef);
+    } else {
+        const uint32_t *ll = kth == 0 ? coef : ((kth - 1) & 1) ? t1 : t0;
+        uint32_t *out = (kth & 1) ? t1 : t0;
+        dim3 g((P.lh[lev] + TILE_W - 1) / TILE_W, (P.lv[lev] + TILE_H - 1) / TILE_H, P.nplanes);
+        hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, s, (const DwtTileArgs *)d_tab, ll,
+                           (const uint32_t *)coef, out);
+    }
+}
+
+/* returns which buffer (0 coef, 1 t0, 2 t1) holds the result */
+static int planeset_run(const PlaneSet &P, int mode, uint8_t *d_tabs, const std::vector<size_t> &tab_off,
+                        uint32_t *coef, uint32_t *t0, uint32_t *t1, hipStream_t s)
+{
+    int kth = 0;
+    for (int lev = 0; lev < P.levels; lev++) {
+        if (P.lh[lev] <= 0 || P.lv[lev] <= 0) continue;
+        const void *tab = d_tabs + tab_off[lev];
+        if (P.type == J2K_DWT53) planeset_launch_level<J2K_DWT53>(P, lev, mode, kth, tab, coef, t0, t1, s);
+        else if (P.type == J2K_DWT97) planeset_launch_level<J2K_DWT97>(P, lev, mode, kth, tab, coef, t0, t1, s);
+        else planeset_launch_level<J2K_DWT97_INT>(P, lev, mode, kth, tab, coef, t0, t1, s);
+        kth++;
+    }
+    if (mode == 0 || kth == 0) return 0;
+    return 1 + ((kth - 1) & 1);
+}
+
+static int planeset_upload_tables(htj2k_ctx *c, const PlaneSet &P, int mode, DevBuf &d_tabs, std::vector<size_t> &off)
+{
+    std::vector<uint8_t> all;
+    off.clear();
+    for (int lev = 0; lev < P.levels; lev++) {
+        while (all.size() % 16) all.push_back(0);
+        off.push_back(all.size());
+        const std::vector<uint8_t> &t = mode == 0 ? P.tables_generic[lev] : P.tables_tile[lev];
+        all.insert(all.end(), t.begin(), t.end());
+    }
+    int r = d_tabs.ensure(all.size() + 64);
+    if (r < 0) return r;
+    if (!all.empty()) HIP_TRY(c, hipMemcpy(d_tabs.p, all.data(), all.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int htj2k_idwt_plane(htj2k_ctx *c, void *plane, const int border[2][2], int levels, int type)
+{
+    if (!c || !plane || levels < 0 || levels > J2K_MAX_DWTLEV || type < 0 || type > 2) return HTJ2K_ERR_EINVAL;
+    if (border[0][1] <= border[0][0] || border[1][1] <= border[1][0]) return HTJ2K_ERR_EINVAL;
+    if (levels == 0) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    PlaneSet P;
+    planeset_build(P, border, levels, type, 1);
+    DevBuf coef, t0, t1, tabs;
+    std::vector<size_t> off;
+    const size_t bytes = P.plane_samples * 4 + 256;
+    int r;
+    if ((r = coef.ensure(bytes)) < 0 || (r = t0.ensure(bytes)) < 0 || (r = t1.ensure(bytes)) < 0 ||
+        (r = planeset_upload_tables(c, P, c->idwt_mode, tabs, off)) < 0) {
+        coef.release(); t0.release(); t1.release(); tabs.release();
+        return r;
+    }
+    hipError_t e = hipMemcpy(coef.p, plane, (size_t)P.w * P.h * 4, hipMemcpyHostToDevice);
+    int fb = 0;
+    if (e == hipSuccess) {
+        fb = planeset_run(P, c->idwt_mode, (uint8_t *)tabs.p, off, (uint32_t *)coef.p, (uint32_t *)t0.p, (uint32_t *)t1.p, 0);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy(plane, fb == 0 ? coef.p : fb == 1 ? t0.p : t1.p, (size_t)P.w * P.h * 4, hipMemcpyDeviceToHost);
+    coef.release(); t0.release(); t1.release(); tabs.release();
+    if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_idwt_plane\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
+    return 0;
+}
+
+__global__ void k_fill_pattern(uint32_t *p, size_t n, int is_float)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    int v = (int)(h % 511u) - 255;
+    p[i] = is_float ? __float_as_uint((float)v * 0.25f) : (uint32_t)v;
+}
+
+extern "C" int htj2k_idwt_bench(htj2k_ctx *c, int w, int h, int levels, int type, int nplanes, int iters, float *ms_per_iter)
+{
+    if (!c || w <= 0 || h <= 0 || levels <= 0 || levels > J2K_MAX_DWTLEV || type < 0 || type > 2 || nplanes <= 0 || iters <= 0 || !ms_per_iter)
+        return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int border[2][2] = { { 0, w }, { 0, h } };
+    PlaneSet P;
+    planeset_build(P, border, levels, type, nplanes);
+    DevBuf coef, t0, t1, tabs;
+    std::vector<size_t> off;
+    const size_t n = P.plane_samples * nplanes, bytes = n * 4 + 256;
+    int r;
+    if ((r = coef.ensure(bytes)) < 0 || (r = t0.ensure(bytes)) < 0 || (r = t1.ensure(bytes)) < 0 ||
+        (r = planeset_upload_tables(c, P, c->idwt_mode, tabs, off)) < 0) {
+        coef.release(); t0.release(); t1.release(); tabs.release();
+        return r;
+    }
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fill_pattern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint32_t *)coef.p, n, type == J2K_DWT97);
+        planeset_run(P, c->idwt_mode, (uint8_t *)tabs.p, off, (uint32_t *)coef.p, (uint32_t *)t0.p, (uint32_t *)t1.p, s);   /* warm-up */
+        e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters; i++)
+            planeset_run(P, c->idwt_mode, (uint8_t *)tabs.p, off, (uint32_t *)coef.p, (uint32_t *)t0.p, (uint32_t *)t1.p, s);
+        (void)hipEventRecord(e1, s);
+        e = hipStreamSynchronize(s);
+    }
+    float ms = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    coef.release(); t0.release(); t1.release(); tabs.release();
+    if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_idwt_bench\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
+    *ms_per_iter = ms / iters;
+    return 0;
+}
+
+extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int csize, int type)
+{
+    if (!c || !p0 || !p1 || !p2 || csize <= 0 || type < 0 || type > 2) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf d[3];
+    void *h[3] = { p0, p1, p2 };
+    int r = 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 3 && r >= 0; i++) r = d[i].ensure((size_t)csize * 4);
+    for (int i = 0; i < 3 && r >= 0 && e == hipSuccess; i++) e = hipMemcpy(d[i].p, h[i], (size_t)csize * 4, hipMemcpyHostToDevice);
+    if (r >= 0 && e == hipSuccess) {
+        hipLaunchKernelGGL(k_mct_only, dim3((csize + 255) / 256), dim3(256), 0, 0, (uint32_t *)d[0].p, (uint32_t *)d[1].p, (uint32_t *)d[2].p, csize, type);
+        e = hipDeviceSynchronize();
+    }
+    for (int i = 0; i < 3 && r >= 0 && e == hipSuccess; i++) e = hipMemcpy(h[i], d[i].p, (size_t)csize * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 3; i++) d[i].release();
+    if (r < 0) return r;
+    return e == hipSuccess ? 0 : HTJ2K_ERR_EXTERNAL;
+}
+
+/* HT block decoder alone: decode `n` codeblocks given as a descriptor table + byte pool into
+ * a sample buffer (unit parity against ff_jpeg2000_decode_htj2k + dequantisation) */
+extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, const uint8_t *bytes, size_t nbytes,
+                               void *coef, size_t nsamples, int *status)
+{
+    if (!c || !blocks || nblocks <= 0 || !bytes || !coef) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    htj2k_job tmp;
+    J2kPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.blocks = (J2kBlock *)blocks; pl.nblocks = nblocks; pl.bytes = (uint8_t *)bytes; pl.nbytes = nbytes;
+    tmp.plan = &pl;
+    int r = build_ht_lds(c, &tmp);
+    if (r < 0) return r;
+    DevBuf db, dby, dc, ds;
+    if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
+        (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0) {
+        db.release(); dby.release(); dc.release(); ds.release();
+        return r;
+    }
+    hipError_t e = hipMemcpy(db.p, blocks, (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dby.p, bytes, nbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
+    if (e == hipSuccess && (int)tmp.lds.total > 48 * 1024)
+        e = hipFuncSetAttribute((const void *)k_ht_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.lds.total);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_ht_decode, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
+                           (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
+    db.release(); dby.release(); dc.release(); ds.release();
+    tmp.plan = nullptr;
+    if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_ht_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
+    return 0;
+}

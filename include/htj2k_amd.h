@@ -166,6 +166,21 @@ int  htj2k_idwt_bench(htj2k_ctx *ctx, int w, int h, int decomp_levels, int type,
 /* Jpeg2000DSPContext.mct_decode[type] (jpeg2000dsp.c:43-91) on host planes */
 int  htj2k_mct_planes(htj2k_ctx *ctx, void *p0, void *p1, void *p2, int csize, int type);
 
+/* ff_jpeg2000_decode_htj2k() + dequantisation (jpeg2000htdec.c:1188, jpeg2000dec.c:2098-2181)
+ * on a caller-built table of `nblocks` 32-byte codeblock descriptors (layout: struct J2kBlock
+ * in ffmpeg-ht_amd/csrc/j2k_plan.h) over a byte pool, into `coef` (nsamples 32-bit samples).
+ * status[i] != 0: block i was rejected and left zero. */
+int  htj2k_ht_blocks(htj2k_ctx *ctx, const void *blocks, int nblocks, const uint8_t *bytes, size_t nbytes,
+                     void *coef, size_t nsamples, int *status);
+/* codeblocks the HT decoder rejected in the job's last run (they are left zero) */
+int  htj2k_job_block_errors(htj2k_ctx *ctx, htj2k_job *job);
+int  htj2k_job_num_blocks(const htj2k_job *job);
+/* device address of an output plane, for callers that keep decoded frames on the GPU */
+void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
+/* tuning / test knobs: "idwt_mode" (0 generic kernels, 1 fused LDS tile kernels),
+ * "bitexact", "reduction_factor" */
+int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
+
 const char *htj2k_version(void);
 /* name of the device the context is bound to, e.g. "gfx950" */
 const char *htj2k_device_name(htj2k_ctx *ctx);
