@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixel/s of the MI355X-native HTJ2K decode hot path on BASELINE.json configs[1]
+(3840x2160 RGB 8-bit, lossless 5/3 + RCT, 64x64 codeblocks, 5 levels), device-resident.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path -- HT block decode + dequantisation, inverse DWT, inverse
+RCT + level shift + clip + rgb24 pack (tile_codeblocks() + the tail of jpeg2000_decode_tile(),
+libavcodec/jpeg2000dec.c:2212-2395) -- over one batch of BATCH synthetic 4K frames whose
+compressed codeblock bytes and descriptors are already resident in HBM when the timed region
+starts; decoded frames stay in HBM.  Host marker/Tier-2 parsing and PCIe are outside the
+timed region (their rates are reported as extra fields and in DESIGN.md, never as `value`).
+
+Frames of a stream are independent, so ranks shard them round-robin with no data-path
+collective ("weak" scaling: every rank decodes its own batch per step).
+
+The JSON line also carries
+  roofline      the IDWT kernel (the HBM-bound kernel BASELINE.json's metric names): algorithmic
+                bytes (sum over levels of 2*4*lh*lv per plane) / its launch duration,
+                measured live with HIP events around every launch of the timed region on the
+                kernel's own stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU oracle (a single-thread C restatement of the reference decoder:
+                kind "port") timed on this box's host cores on a bounded sample of the same
+                workload -- test infrastructure used here only as the measured baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WIDTH, HEIGHT, NCOMP = 3840, 2160, 3
+NLEVELS, CB = 5, (6, 6)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def shard_frames(nframes, rank, world):
+    """frame i -> rank i mod world"""
+    return list(range(rank, nframes, world))
+
+
+def max_over_ranks(seconds):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def make_streams(nstreams, rank):
+    """distinct synthetic 4K RGB frames (BASELINE.md section 3 generator) -> HTJ2K codestreams"""
+    import vecgen
+    out = []
+    for i in range(nstreams):
+        img = vecgen.synth_image(WIDTH, HEIGHT, NCOMP, depth=8, seed=2 + i + 16 * rank, noise=8)
+        out.append(vecgen.encode(img, mct=1, nlevels=NLEVELS, cb=CB, transform=1))
+    return out
+
+
+def cpu_baseline(streams, budget_s=12.0):
+    """single-thread CPU oracle on a bounded sample of the same frames"""
+    import oracle
+    orc = oracle.OracleDecoder()
+    orc.decode(streams[0])                      # warm caches / page in
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.decode(streams[n % len(streams)])
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    orc.close()
+    return {"value": round(n * WIDTH * HEIGHT / el / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d decodes of the bench's 4K RGB lossless frames in %.1f s, single thread, "
+                      "oracle/j2k_oracle.c (C restatement of the reference decoder incl. host parsing)" % (n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="4K frames per step and per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank (cycled to fill the batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    import ffmpeg_ht_amd as m
+
+    streams = make_streams(min(args.distinct, args.batch), rank)
+    batch = [streams[i % len(streams)] for i in range(args.batch)]
+
+    dec = m.Decoder(device_id=local_rank if world > 1 else 0)
+    t0 = time.perf_counter()
+    job = dec.job().parse_batch(batch)
+    t_parse = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    job.upload().wait()
+    t_upload = time.perf_counter() - t0
+    nblocks = job.num_blocks()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.run(7)
+    job.wait()
+    # parity spot-check of what is being timed: frame 0 of the batch is lossless vs its source
+    barrier()
+    t0 = time.perf_counter()
+    ht_ms = idwt_ms = pack_ms = 0.0
+    idwt_launch_ms, idwt_launch_bytes = 0.0, 0.0
+    nlaunch = 0
+    for _ in range(args.steps):
+        job.run(7)
+        # the per-stage / per-launch HIP events are read after the step's stream work is done
+        a, b, c = job.stage_ms()
+        ht_ms += a
+        idwt_ms += b
+        pack_ms += c
+        for ms, by in job.idwt_launches():
+            idwt_launch_ms += ms
+            idwt_launch_bytes += by
+            nlaunch += 1
+    job.wait()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    frames_total = args.steps * args.batch * world
+    value = frames_total * WIDTH * HEIGHT / elapsed / 1e6
+
+    # end-to-end rate of one frame through the plain htj2k_decode() entry (parse + H2D + kernels + D2H)
+    t0 = time.perf_counter()
+    n_e2e = 3
+    for i in range(n_e2e):
+        dec.decode(streams[i % len(streams)])
+    e2e = n_e2e * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6
+
+    if rank == 0:
+        achieved = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
+        res = {
+            "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3)",
+            "value": round(value, 2),
+            "unit": "Mpixel/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 3840x2160 RGB 8-bit lossless 5/3 + RCT, 64x64 codeblocks, 5 levels, "
+                                   "single tile, HT cleanup pass only; %d frames per step per GPU, device-resident "
+                                   "input (codeblock bytes + descriptors) and output (rgb24)" % args.batch,
+                       "frames_per_step": args.batch, "codeblocks_per_step": nblocks,
+                       "sharding": "frames round-robin over ranks, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_idwt_tile<5/3> (all levels)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": nlaunch, "avg_launch_us": round(idwt_launch_ms / max(nlaunch, 1) * 1e3, 2),
+                         "algorithmic_MB_per_launch": round(idwt_launch_bytes / max(nlaunch, 1) / 1e6, 3)},
+            "stage_ms_per_step": {"ht_decode_dequant": round(ht_ms / args.steps, 4), "idwt": round(idwt_ms / args.steps, 4),
+                                  "mct_pack": round(pack_ms / args.steps, 4)},
+            "host": {"parse_ms_per_frame": round(t_parse / args.batch * 1e3, 3),
+                     "h2d_ms_per_frame": round(t_upload / args.batch * 1e3, 3),
+                     "end_to_end_Mpixel_s_single_frame_calls": round(e2e, 1)},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(streams)
+        print(json.dumps(res), flush=True)
+    job.free()
+    dec.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,7 +74,9 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_bytes_consumed", "htj2k_job_free", "htj2k_job_num_tilecomps", "htj2k_job_tilecomp_dims",
            "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
            "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_job_block_errors",
-           "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name"]
+           "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
+           "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
+           "htj2k_job_idwt_launches"]
 
 _lib = None
 
@@ -118,6 +120,36 @@ class Job:
         self._buf = _pkt(data)
         _check(self.dec.L.htj2k_job_parse(self.dec.h, self._buf, len(data), ctypes.byref(self.h)), "htj2k_job_parse")
         return self
+
+    def parse_batch(self, datas):
+        """several independent frames -> one job whose stages are single launches over the whole batch"""
+        n = len(datas)
+        self._bufs = [_pkt(d) for d in datas]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p) for b in self._bufs])
+        sizes = (ctypes.c_int * n)(*[len(d) for d in datas])
+        _check(self.dec.L.htj2k_job_parse_batch(self.dec.h, ptrs, sizes, n, ctypes.byref(self.h)), "htj2k_job_parse_batch")
+        return self
+
+    def num_frames(self):
+        return _check(self.dec.L.htj2k_job_num_frames(self.h), "htj2k_job_num_frames")
+
+    def frame_info(self, f):
+        info = Info()
+        _check(self.dec.L.htj2k_job_frame_info(self.h, f, ctypes.byref(info)), "htj2k_job_frame_info")
+        return info
+
+    def download_frame(self, f):
+        info = self.frame_info(f)
+        planes, fr = alloc_frame(info)
+        _check(self.dec.L.htj2k_job_download_frame(self.dec.h, self.h, f, ctypes.byref(fr)), "htj2k_job_download_frame")
+        return info, planes_to_arrays(info, planes)
+
+    def idwt_launches(self, cap=256):
+        """[(ms, algorithmic_bytes)] of the IDWT launches of the last run"""
+        ms = (ctypes.c_float * cap)()
+        by = (ctypes.c_double * cap)()
+        n = _check(self.dec.L.htj2k_job_idwt_launches(self.dec.h, self.h, ms, by, cap), "htj2k_job_idwt_launches")
+        return [(ms[i], by[i]) for i in range(min(n, cap))]
 
     def upload(self):
         _check(self.dec.L.htj2k_job_upload(self.dec.h, self.h), "htj2k_job_upload")

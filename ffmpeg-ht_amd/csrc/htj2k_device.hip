@@ -57,28 +57,43 @@ struct htj2k_ctx {
     int max_dyn_lds = 64 * 1024;
 };
 
-struct LevelLaunch {                   /* one IDWT launch: all planes of one type that have this level */
+struct LevelLaunch {                   /* one IDWT launch: all planes (of all frames) of one type that have this level */
     int type, level;
     int count;                         /* planes */
-    size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_tables */
+    size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_desc */
     int max_lh, max_lv;
+    double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv */
+};
+
+struct FrameSlot {                     /* one frame of a batch */
+    J2kParser *parser = nullptr;
+    const J2kPlan *plan = nullptr;
+    std::vector<uint8_t> pkt;          /* private copy: the caller's packet is only borrowed for the call */
+    uint32_t block_base = 0, tc_base = 0, sample_base = 0;
+    size_t bytes_base = 0;
+    DevBuf d_out[4];
+    OutPlanes out;
 };
 
 struct htj2k_job {
-    J2kParser *parser = nullptr;
-    const J2kPlan *plan = nullptr;
+    std::vector<FrameSlot> frames;
+    int nframes = 0;
+    /* merged (re-based) tables of the whole batch */
+    std::vector<J2kBlock> blocks;
+    std::vector<J2kTileComp> tilecomps;
+    std::vector<int> tc_frame;         /* frame index of each merged tile-component */
+    size_t nbytes = 0, nsamples = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_out[4];
+    std::vector<hipEvent_t> lev_ev;    /* per-IDWT-launch brackets (roofline measurement) */
+    int lev_ev_used = 0;
+    std::vector<double> lev_bytes;     /* algorithmic bytes of each recorded launch */
+    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc;
     std::vector<uint8_t> h_desc;       /* host image of d_desc: level tables + pack tiles */
     std::vector<LevelLaunch> launches_generic, launches_tile;
     size_t pack_off = 0; int npack = 0; int pack_maxw = 0, pack_maxh = 0;
-    size_t pack_off_generic = 0;
-    OutPlanes out;
     HtLds lds;
     int uploaded = 0, ran = 0;
-    float ms_ht = 0, ms_idwt = 0, ms_pack = 0;
-    int n_block_errors = 0;
     std::vector<int> final_buf;        /* per tilecomp, tile mode: 0 = coef, 1 = t0, 2 = t1 */
     std::vector<int> final_eff;        /* where each plane actually is after the last IDWT run */
     bool tile_ok = true;               /* no empty levels: all planes of a launch ping-pong in step */
@@ -192,10 +207,13 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     if (j->stream) (void)hipStreamSynchronize(j->stream);
     j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
     j->d_t0.release(); j->d_t1.release(); j->d_desc.release();
-    for (int i = 0; i < 4; i++) j->d_out[i].release();
+    for (FrameSlot &f : j->frames) {
+        for (int i = 0; i < 4; i++) f.d_out[i].release();
+        j2k_parser_free(f.parser);
+    }
     for (int i = 0; i < 6; i++) if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
+    for (hipEvent_t e : j->lev_ev) if (e) (void)hipEventDestroy(e);
     if (j->stream) (void)hipStreamDestroy(j->stream);
-    j2k_parser_free(j->parser);
     delete j;
 }
 
@@ -224,11 +242,8 @@ static int job_new(htj2k_ctx *c, htj2k_job **out)
 {
     htj2k_job *j = new (std::nothrow) htj2k_job();
     if (!j) return HTJ2K_ERR_ENOMEM;
-    j->parser = j2k_parser_new();
-    if (!j->parser) { delete j; return HTJ2K_ERR_ENOMEM; }
-    j2k_parser_set_log(j->parser, parser_log_tramp, c);
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) {
-        j2k_parser_free(j->parser); delete j; return HTJ2K_ERR_EXTERNAL;
+        delete j; return HTJ2K_ERR_EXTERNAL;
     }
     for (int i = 0; i < 6; i++)
         if (hipEventCreate(&j->ev[i]) != hipSuccess) { htj2k_job_free(c, j); return HTJ2K_ERR_EXTERNAL; }
@@ -236,53 +251,113 @@ static int job_new(htj2k_ctx *c, htj2k_job **out)
     return 0;
 }
 
-extern "C" int htj2k_job_parse(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_job **job)
+/* A job holds a batch of frames.  Every frame is parsed by its own parser; the descriptor
+ * tables are then concatenated (offsets re-based into one device arena) so that each stage
+ * of the whole batch is a single launch: frames are independent, so a batch is simply a
+ * longer codeblock table, more planes per IDWT level, more tiles to pack. */
+extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, const int *sizes, int n, htj2k_job **job)
 {
-    if (!c || !pkt || !job) return HTJ2K_ERR_EINVAL;
+    if (!c || !pkts || !sizes || n <= 0 || !job) return HTJ2K_ERR_EINVAL;
     if (!*job) {
         int r = job_new(c, job);
         if (r < 0) return r;
     }
     htj2k_job *j = *job;
-    /* the previous frame of this job may still be in flight and reads the parser's arena */
+    /* the previous batch of this job may still be in flight and reads the parsers' arenas */
     if (hipStreamSynchronize(j->stream) != hipSuccess) return HTJ2K_ERR_EXTERNAL;
     j->uploaded = j->ran = 0;
-    j->plan = nullptr;
-    return j2k_parse(j->parser, pkt, size, &c->opts, 0, &j->plan);
-}
-
-extern "C" int htj2k_job_info(const htj2k_job *j, htj2k_info *info)
-{
-    if (!j || !j->plan || !info) return HTJ2K_ERR_EINVAL;
-    *info = j->plan->info;
+    j->nframes = 0;
+    if ((int)j->frames.size() < n) j->frames.resize(n);
+    j->blocks.clear(); j->tilecomps.clear(); j->tc_frame.clear();
+    size_t nbytes = 0, nsamples = 0;
+    for (int f = 0; f < n; f++) {
+        FrameSlot &F = j->frames[f];
+        if (!F.parser) {
+            F.parser = j2k_parser_new();
+            if (!F.parser) return HTJ2K_ERR_ENOMEM;
+            j2k_parser_set_log(F.parser, parser_log_tramp, c);
+        }
+        F.plan = nullptr;
+        int r = j2k_parse(F.parser, pkts[f], sizes[f], &c->opts, 0, &F.plan);
+        if (r < 0) return r;
+        const J2kPlan *pl = F.plan;
+        if (nsamples + pl->nsamples > 0xFFFFFF00ull || nbytes + pl->nbytes > 0xFFFFFF00ull ||
+            j->tilecomps.size() + pl->ntilecomps > 250)      /* J2kBlock.tcomp is a byte */
+            return HTJ2K_ERR_PATCHWELCOME;
+        F.block_base = (uint32_t)j->blocks.size();
+        F.tc_base = (uint32_t)j->tilecomps.size();
+        F.sample_base = (uint32_t)nsamples;
+        F.bytes_base = nbytes;
+        for (int i = 0; i < pl->nblocks; i++) {
+            J2kBlock b = pl->blocks[i];
+            b.data_off += (uint32_t)nbytes;
+            b.plane_off += (uint32_t)nsamples;
+            b.tcomp = (uint8_t)(b.tcomp + F.tc_base);
+            j->blocks.push_back(b);
+        }
+        for (int t = 0; t < pl->ntilecomps; t++) {
+            J2kTileComp tc = pl->tilecomps[t];
+            tc.plane_off += (uint32_t)nsamples;
+            j->tilecomps.push_back(tc);
+            j->tc_frame.push_back(f);
+        }
+        nbytes += (pl->nbytes + 63) & ~(size_t)63;
+        nsamples += pl->nsamples;
+    }
+    j->nbytes = nbytes;
+    j->nsamples = nsamples;
+    j->nframes = n;
     return 0;
 }
-extern "C" int htj2k_job_bytes_consumed(const htj2k_job *j) { return j && j->plan ? j->plan->bytes_consumed : HTJ2K_ERR_EINVAL; }
-extern "C" int htj2k_job_num_tilecomps(const htj2k_job *j) { return j && j->plan ? j->plan->ntilecomps : HTJ2K_ERR_EINVAL; }
-extern "C" int htj2k_job_num_blocks(const htj2k_job *j) { return j && j->plan ? j->plan->nblocks : HTJ2K_ERR_EINVAL; }
+
+extern "C" int htj2k_job_parse(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_job **job)
+{
+    const uint8_t *pk[1] = { pkt };
+    int sz[1] = { size };
+    if (!pkt) return HTJ2K_ERR_EINVAL;
+    return htj2k_job_parse_batch(c, pk, sz, 1, job);
+}
+
+extern "C" int htj2k_job_num_frames(const htj2k_job *j) { return j ? j->nframes : HTJ2K_ERR_EINVAL; }
+
+extern "C" int htj2k_job_frame_info(const htj2k_job *j, int frame, htj2k_info *info)
+{
+    if (!j || frame < 0 || frame >= j->nframes || !j->frames[frame].plan || !info) return HTJ2K_ERR_EINVAL;
+    *info = j->frames[frame].plan->info;
+    return 0;
+}
+extern "C" int htj2k_job_info(const htj2k_job *j, htj2k_info *info) { return htj2k_job_frame_info(j, 0, info); }
+extern "C" int htj2k_job_bytes_consumed(const htj2k_job *j)
+{
+    return j && j->nframes > 0 && j->frames[0].plan ? j->frames[0].plan->bytes_consumed : HTJ2K_ERR_EINVAL;
+}
+extern "C" int htj2k_job_num_tilecomps(const htj2k_job *j) { return j && j->nframes ? (int)j->tilecomps.size() : HTJ2K_ERR_EINVAL; }
+extern "C" int htj2k_job_num_blocks(const htj2k_job *j) { return j && j->nframes ? (int)j->blocks.size() : HTJ2K_ERR_EINVAL; }
 extern "C" int htj2k_job_tilecomp_dims(const htj2k_job *j, int tc, int *w, int *h, int *is_float)
 {
-    if (!j || !j->plan || tc < 0 || tc >= j->plan->ntilecomps) return HTJ2K_ERR_EINVAL;
-    if (w) *w = j->plan->tilecomps[tc].w;
-    if (h) *h = j->plan->tilecomps[tc].h;
-    if (is_float) *is_float = j->plan->tilecomps[tc].transform == J2K_DWT97;
+    if (!j || !j->nframes || tc < 0 || tc >= (int)j->tilecomps.size()) return HTJ2K_ERR_EINVAL;
+    if (w) *w = j->tilecomps[tc].w;
+    if (h) *h = j->tilecomps[tc].h;
+    if (is_float) *is_float = j->tilecomps[tc].transform == J2K_DWT97;
     return 0;
 }
 
 /* ------------------------------------------------------------------ job: upload */
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int build_ht_lds(htj2k_ctx *c, htj2k_job *j)
+/* LDS windows of the HT kernel are sized from the largest cleanup prefix / suffix, quad row
+ * and (for blocks with refinement passes) state bitmap in the table */
+static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const uint8_t *const *bases,
+                        const uint32_t *base_of_block, HtLds *out)
 {
-    const J2kPlan *pl = j->plan;
     uint32_t max_p = 0, max_s = 2, max_qw = 1, bm_words = 0;
-    for (int i = 0; i < pl->nblocks; i++) {
-        const J2kBlock &b = pl->blocks[i];
+    for (int i = 0; i < nblocks; i++) {
+        const J2kBlock &b = blocks[i];
         if (!b.npasses) continue;
         uint32_t qw = (b.w + 1u) >> 1;
         if (qw > max_qw) max_qw = qw;
         if (b.lcup >= 2) {
-            const uint8_t *D = pl->bytes + b.data_off;
+            const uint8_t *D = bases[base_of_block ? base_of_block[i] : 0] + b.data_off;
             uint32_t scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
             if (scup >= 2 && scup <= b.lcup && scup <= 4079) {
                 if (scup > max_s) max_s = scup;
@@ -295,7 +370,7 @@ static int build_ht_lds(htj2k_ctx *c, htj2k_job *j)
             if (wds > bm_words) bm_words = wds;
         }
     }
-    HtLds &L = j->lds;
+    HtLds &L = *out;
     size_t off = 4096;                                   /* the two CxtVLC tables */
     L.ms_words = (max_p * 8 + 31) / 32 + 2;
     L.off_ms = (uint32_t)off;  off += (size_t)L.ms_words * 4;
@@ -325,23 +400,22 @@ static void push_bytes(std::vector<uint8_t> &v, const void *p, size_t n)
 /* descriptor tables for the IDWT launches and the pack stage */
 static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
 {
-    const J2kPlan *pl = j->plan;
+    const int ntc = (int)j->tilecomps.size();
     j->h_desc.clear();
     j->launches_generic.clear();
     j->launches_tile.clear();
-    j->final_buf.assign(pl->ntilecomps, 0);
+    j->final_buf.assign(ntc, 0);
     int maxlev = 0;
-    for (int t = 0; t < pl->ntilecomps; t++)
-        if (pl->tilecomps[t].coded && pl->tilecomps[t].ndeclevels > maxlev) maxlev = pl->tilecomps[t].ndeclevels;
+    for (int t = 0; t < ntc; t++)
+        if (j->tilecomps[t].coded && j->tilecomps[t].ndeclevels > maxlev) maxlev = j->tilecomps[t].ndeclevels;
     for (int lev = 0; lev < maxlev; lev++)
         for (int type = 0; type < 3; type++) {
-            LevelLaunch g, tl;
-            g.type = tl.type = type; g.level = tl.level = lev; g.count = tl.count = 0;
-            g.max_lh = g.max_lv = tl.max_lh = tl.max_lv = 0;
+            LevelLaunch g;
+            g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0;
             std::vector<DwtLevel> lv;
             std::vector<DwtTileArgs> ta;
-            for (int t = 0; t < pl->ntilecomps; t++) {
-                const J2kTileComp &tc = pl->tilecomps[t];
+            for (int t = 0; t < ntc; t++) {
+                const J2kTileComp &tc = j->tilecomps[t];
                 if (!tc.coded || tc.transform != type || lev >= tc.ndeclevels) continue;
                 if (tc.linelen[lev][0] <= 0 || tc.linelen[lev][1] <= 0) continue;   /* empty level: no-op */
                 DwtLevel d;
@@ -357,10 +431,11 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                 ta.push_back(a);
                 if (d.lh > g.max_lh) g.max_lh = d.lh;
                 if (d.lv > g.max_lv) g.max_lv = d.lv;
+                g.alg_bytes += 8.0 * d.lh * d.lv;
             }
             if (lv.empty()) continue;
-            g.count = tl.count = (int)lv.size();
-            tl.max_lh = g.max_lh; tl.max_lv = g.max_lv;
+            g.count = (int)lv.size();
+            LevelLaunch tl = g;
             g.table_off = j->h_desc.size();
             push_bytes(j->h_desc, lv.data(), lv.size() * sizeof(DwtLevel));
             while (j->h_desc.size() % 16) j->h_desc.push_back(0);
@@ -370,11 +445,11 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
             j->launches_generic.push_back(g);
             j->launches_tile.push_back(tl);
         }
-    /* tile mode ping-pongs between the two scratch buffers: the level that actually runs
-     * k-th for a plane reads LL from buffer (k-1) and writes buffer k (1 = t0, 2 = t1) */
+    /* tile mode ping-pongs between the two scratch buffers: the level that runs k-th for a
+     * plane reads LL from buffer (k-1) and writes buffer k (1 = t0, 2 = t1) */
     j->tile_ok = true;
-    for (int t = 0; t < pl->ntilecomps; t++) {
-        const J2kTileComp &tc = pl->tilecomps[t];
+    for (int t = 0; t < ntc; t++) {
+        const J2kTileComp &tc = j->tilecomps[t];
         int k = 0;
         if (tc.coded)
             for (int lev = 0; lev < tc.ndeclevels; lev++) {
@@ -383,32 +458,38 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
             }
         j->final_buf[t] = k == 0 ? 0 : 1 + ((k - 1) & 1);
     }
-    j->final_eff.assign(pl->ntilecomps, 0);
-    /* pack tiles: two variants of the source pointers (generic mode ends in coef) are
-     * patched at launch time, so only geometry is stored here */
+    j->final_eff.assign(ntc, 0);
+    /* pack tiles; their source pointers are patched at launch time */
+    while (j->h_desc.size() % 16) j->h_desc.push_back(0);
     j->pack_off = j->h_desc.size();
-    j->npack = pl->ntiles;
+    j->npack = 0;
     j->pack_maxw = j->pack_maxh = 0;
-    for (int ti = 0; ti < pl->ntiles; ti++) {
-        PackTile T;
-        memset(&T, 0, sizeof(T));
-        T.ncomp = pl->info.ncomponents;
-        T.out_bytes = pl->out_bytes;
-        T.precision = pl->out_shift_precision;
-        for (int cc = 0; cc < T.ncomp; cc++) {
-            const J2kTileComp &tc = pl->tilecomps[ti * T.ncomp + cc];
-            PackComp &C = T.c[cc];
-            C.src = nullptr;
-            C.w = tc.w; C.h = tc.h; C.transform = tc.transform; C.cbps = tc.cbps;
-            C.out_plane = tc.out_plane; C.out_x = tc.out_x; C.out_y = tc.out_y;
-            C.pix_step = tc.pix_step; C.pix_off = tc.pix_off;
-            if (tc.w > T.maxw) T.maxw = tc.w;
-            if (tc.h > T.maxh) T.maxh = tc.h;
-            if (cc == 0) T.mct = tc.mct;
+    for (int f = 0; f < j->nframes; f++) {
+        const FrameSlot &F = j->frames[f];
+        const J2kPlan *pl = F.plan;
+        for (int ti = 0; ti < pl->ntiles; ti++) {
+            PackTile T;
+            memset(&T, 0, sizeof(T));
+            T.out = F.out;
+            T.ncomp = pl->info.ncomponents;
+            T.out_bytes = pl->out_bytes;
+            T.precision = pl->out_shift_precision;
+            for (int cc = 0; cc < T.ncomp; cc++) {
+                const J2kTileComp &tc = j->tilecomps[F.tc_base + ti * T.ncomp + cc];
+                PackComp &C = T.c[cc];
+                C.src = nullptr;
+                C.w = tc.w; C.h = tc.h; C.transform = tc.transform; C.cbps = tc.cbps;
+                C.out_plane = tc.out_plane; C.out_x = tc.out_x; C.out_y = tc.out_y;
+                C.pix_step = tc.pix_step; C.pix_off = tc.pix_off;
+                if (tc.w > T.maxw) T.maxw = tc.w;
+                if (tc.h > T.maxh) T.maxh = tc.h;
+                if (cc == 0) T.mct = tc.mct;
+            }
+            if (T.maxw > j->pack_maxw) j->pack_maxw = T.maxw;
+            if (T.maxh > j->pack_maxh) j->pack_maxh = T.maxh;
+            push_bytes(j->h_desc, &T, sizeof(T));
+            j->npack++;
         }
-        if (T.maxw > j->pack_maxw) j->pack_maxw = T.maxw;
-        if (T.maxh > j->pack_maxh) j->pack_maxh = T.maxh;
-        push_bytes(j->h_desc, &T, sizeof(T));
     }
     (void)c;
     return 0;
@@ -416,34 +497,52 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
 
 extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
 {
-    if (!c || !j || !j->plan) return HTJ2K_ERR_EINVAL;
-    const J2kPlan *pl = j->plan;
+    if (!c || !j || j->nframes <= 0) return HTJ2K_ERR_EINVAL;
     int r;
     HIP_TRY(c, hipSetDevice(c->device));
-    if ((r = build_ht_lds(c, j)) < 0) return r;
-    if ((r = build_descriptors(c, j)) < 0) return r;
-    const size_t coef_bytes = (pl->nsamples + 64) * sizeof(uint32_t);
-    if ((r = j->d_bytes.ensure(pl->nbytes + 64)) < 0) return r;
-    if ((r = j->d_blocks.ensure((size_t)(pl->nblocks + 1) * sizeof(J2kBlock))) < 0) return r;
-    if ((r = j->d_status.ensure((size_t)(pl->nblocks + 1) * sizeof(int))) < 0) return r;
+    {
+        std::vector<const uint8_t *> bases(j->nframes);
+        std::vector<uint32_t> bob(j->blocks.size());
+        std::vector<J2kBlock> rel(j->blocks.size());
+        for (int f = 0; f < j->nframes; f++) {
+            const FrameSlot &F = j->frames[f];
+            bases[f] = F.plan->bytes;
+            for (int i = 0; i < F.plan->nblocks; i++) { bob[F.block_base + i] = f; rel[F.block_base + i] = F.plan->blocks[i]; }
+        }
+        if ((r = build_ht_lds(c, rel.data(), (int)rel.size(), bases.data(), bob.data(), &j->lds)) < 0) return r;
+    }
+    const size_t coef_bytes = (j->nsamples + 64) * sizeof(uint32_t);
+    const int nblocks = (int)j->blocks.size();
+    if ((r = j->d_bytes.ensure(j->nbytes + 64)) < 0) return r;
+    if ((r = j->d_blocks.ensure((size_t)(nblocks + 1) * sizeof(J2kBlock))) < 0) return r;
+    if ((r = j->d_status.ensure((size_t)(nblocks + 1) * sizeof(int))) < 0) return r;
     if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t0.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
-    if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
-    memset(&j->out, 0, sizeof(j->out));
-    for (int p = 0; p < pl->info.nplanes; p++) {
-        const int ls = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
-        if ((r = j->d_out[p].ensure((size_t)ls * pl->info.plane_height[p] + 64)) < 0) return r;
-        j->out.ptr[p] = (uint8_t *)j->d_out[p].p;
-        j->out.linesize[p] = ls;
-        j->out.width[p] = pl->info.plane_width[p];
-        j->out.height[p] = pl->info.plane_height[p];
+    for (int f = 0; f < j->nframes; f++) {
+        FrameSlot &F = j->frames[f];
+        const J2kPlan *pl = F.plan;
+        memset(&F.out, 0, sizeof(F.out));
+        for (int p = 0; p < pl->info.nplanes; p++) {
+            const int ls = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
+            if ((r = F.d_out[p].ensure((size_t)ls * pl->info.plane_height[p] + 64)) < 0) return r;
+            F.out.ptr[p] = (uint8_t *)F.d_out[p].p;
+            F.out.linesize[p] = ls;
+            F.out.width[p] = pl->info.plane_width[p];
+            F.out.height[p] = pl->info.plane_height[p];
+        }
     }
+    if ((r = build_descriptors(c, j)) < 0) return r;
+    if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
-    if (pl->nbytes)
-        HIP_TRY(c, hipMemcpyAsync(j->d_bytes.p, pl->bytes, pl->nbytes, hipMemcpyHostToDevice, j->stream));
-    if (pl->nblocks)
-        HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, pl->blocks, (size_t)pl->nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
+    for (int f = 0; f < j->nframes; f++) {
+        const FrameSlot &F = j->frames[f];
+        if (F.plan->nbytes)
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_bytes.p + F.bytes_base, F.plan->bytes, F.plan->nbytes,
+                                      hipMemcpyHostToDevice, j->stream));
+    }
+    if (nblocks)
+        HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, j->blocks.data(), (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
     HIP_TRY(c, hipEventRecord(j->ev[1], j->stream));
     j->uploaded = 1;
     return 0;
@@ -476,40 +575,56 @@ static void launch_tile_level(htj2k_job *j, const LevelLaunch &L, const uint32_t
                        (const uint32_t *)j->d_coef.p, out);
 }
 
+static hipEvent_t lev_event(htj2k_job *j)
+{
+    if (j->lev_ev_used >= (int)j->lev_ev.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        j->lev_ev.push_back(e);
+    }
+    return j->lev_ev[j->lev_ev_used++];
+}
+
 static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile)
 {
     (void)c;
-    if (!use_tile) {
-        for (const LevelLaunch &L : j->launches_generic) {
+    j->lev_ev_used = 0;
+    j->lev_bytes.clear();
+    const std::vector<LevelLaunch> &LL = use_tile ? j->launches_tile : j->launches_generic;
+    for (const LevelLaunch &L : LL) {
+        hipEvent_t e0 = lev_event(j);
+        if (e0) (void)hipEventRecord(e0, j->stream);
+        if (!use_tile) {
             if (L.type == J2K_DWT53) launch_generic_level<J2K_DWT53>(j, L);
             else if (L.type == J2K_DWT97) launch_generic_level<J2K_DWT97>(j, L);
             else launch_generic_level<J2K_DWT97_INT>(j, L);
+        } else {
+            const uint32_t *ll = buf_ptr(j, L.level == 0 ? 0 : 1 + ((L.level - 1) & 1));
+            uint32_t *out = buf_ptr(j, 1 + (L.level & 1));
+            if (L.type == J2K_DWT53) launch_tile_level<J2K_DWT53>(j, L, ll, out);
+            else if (L.type == J2K_DWT97) launch_tile_level<J2K_DWT97>(j, L, ll, out);
+            else launch_tile_level<J2K_DWT97_INT>(j, L, ll, out);
         }
-        return 0;
-    }
-    for (const LevelLaunch &L : j->launches_tile) {
-        const uint32_t *ll = buf_ptr(j, L.level == 0 ? 0 : 1 + ((L.level - 1) & 1));
-        uint32_t *out = buf_ptr(j, 1 + (L.level & 1));
-        if (L.type == J2K_DWT53) launch_tile_level<J2K_DWT53>(j, L, ll, out);
-        else if (L.type == J2K_DWT97) launch_tile_level<J2K_DWT97>(j, L, ll, out);
-        else launch_tile_level<J2K_DWT97_INT>(j, L, ll, out);
+        hipEvent_t e1 = lev_event(j);
+        if (e1) (void)hipEventRecord(e1, j->stream);
+        j->lev_bytes.push_back(L.alg_bytes);
     }
     return 0;
 }
 
 extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
 {
-    if (!c || !j || !j->plan || !j->uploaded) return HTJ2K_ERR_EINVAL;
-    const J2kPlan *pl = j->plan;
+    if (!c || !j || j->nframes <= 0 || !j->uploaded) return HTJ2K_ERR_EINVAL;
+    const int nblocks = (int)j->blocks.size(), ntc = (int)j->tilecomps.size();
     HIP_TRY(c, hipSetDevice(c->device));
     if (mask & 1) {
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
-        if (pl->nblocks) {
-            HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)pl->nblocks * sizeof(int), j->stream));
+        if (nblocks) {
+            HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
             if ((int)j->lds.total > 48 * 1024)
                 HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
-            hipLaunchKernelGGL(k_ht_decode, dim3(pl->nblocks), dim3(64), j->lds.total, j->stream,
-                               (const J2kBlock *)j->d_blocks.p, pl->nblocks, (const uint8_t *)j->d_bytes.p,
+            hipLaunchKernelGGL(k_ht_decode, dim3(nblocks), dim3(64), j->lds.total, j->stream,
+                               (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds);
             HIP_TRY(c, hipGetLastError());
         }
@@ -518,15 +633,19 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
     if (mask & 6) {
         const bool use_tile = c->idwt_mode != 0 && j->tile_ok;
         if (mask & 2)
-            for (int t = 0; t < pl->ntilecomps; t++) j->final_eff[t] = use_tile ? j->final_buf[t] : 0;
+            for (int t = 0; t < ntc; t++) j->final_eff[t] = use_tile ? j->final_buf[t] : 0;
         /* one upload of all descriptor tables, pack source pointers patched for where the
          * planes are (or will be) after the IDWT */
         PackTile *T = (PackTile *)(j->h_desc.data() + j->pack_off);
-        for (int ti = 0; ti < pl->ntiles; ti++)
-            for (int cc = 0; cc < T[ti].ncomp; cc++) {
-                const int t = ti * T[ti].ncomp + cc;
-                T[ti].c[cc].src = buf_ptr(j, j->final_eff[t]) + pl->tilecomps[t].plane_off;
-            }
+        int ti = 0;
+        for (int f = 0; f < j->nframes; f++) {
+            const FrameSlot &F = j->frames[f];
+            for (int k = 0; k < F.plan->ntiles; k++, ti++)
+                for (int cc = 0; cc < T[ti].ncomp; cc++) {
+                    const int t = F.tc_base + k * T[ti].ncomp + cc;
+                    T[ti].c[cc].src = buf_ptr(j, j->final_eff[t]) + j->tilecomps[t].plane_off;
+                }
+        }
         if (!(mask & 1)) HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
         HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
         if (mask & 2) {
@@ -540,7 +659,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         if (j->npack && j->pack_maxw > 0 && j->pack_maxh > 0) {
             dim3 g((j->pack_maxw + 255) / 256, j->pack_maxh, j->npack);
             hipLaunchKernelGGL(k_mct_pack, g, dim3(256), 0, j->stream,
-                               (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off), j->out);
+                               (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off));
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(j->ev[5], j->stream));
@@ -572,10 +691,26 @@ extern "C" int htj2k_job_stage_ms(htj2k_ctx *c, htj2k_job *j, float *ms_ht, floa
     return 0;
 }
 
+/* per-launch device time and algorithmic bytes (2 * 4 * lh * lv summed over the planes of
+ * the launch) of the IDWT kernels of the job's last run: the roofline inputs of bench.py */
+extern "C" int htj2k_job_idwt_launches(htj2k_ctx *c, htj2k_job *j, float *ms, double *bytes, int cap)
+{
+    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    const int n = (int)j->lev_bytes.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, j->lev_ev[2 * i], j->lev_ev[2 * i + 1]);
+        if (ms) ms[i] = t;
+        if (bytes) bytes[i] = j->lev_bytes[i];
+    }
+    return n;
+}
+
 extern "C" int htj2k_job_block_errors(htj2k_ctx *c, htj2k_job *j)
 {
-    if (!c || !j || !j->plan) return HTJ2K_ERR_EINVAL;
-    const int n = j->plan->nblocks;
+    if (!c || !j || j->nframes <= 0) return HTJ2K_ERR_EINVAL;
+    const int n = (int)j->blocks.size();
     if (!n) return 0;
     std::vector<int> st(n);
     HIP_TRY(c, hipStreamSynchronize(j->stream));
@@ -587,8 +722,8 @@ extern "C" int htj2k_job_block_errors(htj2k_ctx *c, htj2k_job *j)
 
 extern "C" int htj2k_job_read_plane(htj2k_ctx *c, htj2k_job *j, int tc, void *dst, size_t dst_bytes)
 {
-    if (!c || !j || !j->plan || tc < 0 || tc >= j->plan->ntilecomps) return HTJ2K_ERR_EINVAL;
-    const J2kTileComp &t = j->plan->tilecomps[tc];
+    if (!c || !j || j->nframes <= 0 || tc < 0 || tc >= (int)j->tilecomps.size()) return HTJ2K_ERR_EINVAL;
+    const J2kTileComp &t = j->tilecomps[tc];
     const size_t n = (size_t)t.w * t.h * 4;
     if (dst_bytes < n) return HTJ2K_ERR_EINVAL;
     const int fb = j->final_eff.empty() ? 0 : j->final_eff[tc];
@@ -597,14 +732,15 @@ extern "C" int htj2k_job_read_plane(htj2k_ctx *c, htj2k_job *j, int tc, void *ds
     return 0;
 }
 
-extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame)
+extern "C" int htj2k_job_download_frame(htj2k_ctx *c, htj2k_job *j, int f, htj2k_frame *frame)
 {
-    if (!c || !j || !j->plan || !frame) return HTJ2K_ERR_EINVAL;
-    const J2kPlan *pl = j->plan;
+    if (!c || !j || f < 0 || f >= j->nframes || !frame) return HTJ2K_ERR_EINVAL;
+    const FrameSlot &F = j->frames[f];
+    const J2kPlan *pl = F.plan;
     for (int p = 0; p < pl->info.nplanes; p++) {
         const int rowbytes = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
         if (!frame->data[p] || frame->linesize[p] < rowbytes) return HTJ2K_ERR_EINVAL;
-        HIP_TRY(c, hipMemcpy2DAsync(frame->data[p], frame->linesize[p], j->d_out[p].p, j->out.linesize[p],
+        HIP_TRY(c, hipMemcpy2DAsync(frame->data[p], frame->linesize[p], F.d_out[p].p, F.out.linesize[p],
                                     rowbytes, pl->info.plane_height[p], hipMemcpyDeviceToHost, j->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(j->stream));
@@ -614,12 +750,17 @@ extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame
     return 0;
 }
 
-/* device address of an output plane (for callers that keep frames on the GPU) */
+extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame)
+{
+    return htj2k_job_download_frame(c, j, 0, frame);
+}
+
+/* device address of an output plane of frame 0 (for callers that keep frames on the GPU) */
 extern "C" void *htj2k_job_device_plane(htj2k_job *j, int plane, int *linesize)
 {
-    if (!j || plane < 0 || plane > 3) return nullptr;
-    if (linesize) *linesize = j->out.linesize[plane];
-    return j->out.ptr[plane];
+    if (!j || j->nframes <= 0 || plane < 0 || plane > 3) return nullptr;
+    if (linesize) *linesize = j->frames[0].out.linesize[plane];
+    return j->frames[0].out.ptr[plane];
 }
 
 /* ------------------------------------------------------------------ one-call decode */
@@ -641,7 +782,7 @@ extern "C" int htj2k_decode(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_fr
         clog(c, LOG_ERROR, "Bad HT cleanup segment in %d codeblock(s)\n", nerr);   /* jpeg2000htdec.c:1305 */
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->n_codeblocks = j->plan->nblocks;
+        stats->n_codeblocks = (int)j->blocks.size();
         stats->n_block_errors = nerr > 0 ? nerr : 0;
         stats->ms_parse = std::chrono::duration<float, std::milli>(t1 - t0).count();
         (void)hipEventElapsedTime(&stats->ms_h2d, j->ev[0], j->ev[1]);
@@ -649,7 +790,7 @@ extern "C" int htj2k_decode(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k_fr
         stats->ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
         htj2k_job_stage_ms(c, j, &stats->ms_ht, &stats->ms_idwt, &stats->ms_pack);
     }
-    return j->plan->bytes_consumed;
+    return j->frames[0].plan->bytes_consumed;
 }
 
 /* ------------------------------------------------------------------ kernel-level entry points */
@@ -859,12 +1000,9 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
 {
     if (!c || !blocks || nblocks <= 0 || !bytes || !coef) return HTJ2K_ERR_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    htj2k_job tmp;
-    J2kPlan pl;
-    memset(&pl, 0, sizeof(pl));
-    pl.blocks = (J2kBlock *)blocks; pl.nblocks = nblocks; pl.bytes = (uint8_t *)bytes; pl.nbytes = nbytes;
-    tmp.plan = &pl;
-    int r = build_ht_lds(c, &tmp);
+    struct { HtLds lds; } tmp;
+    const uint8_t *bases[1] = { bytes };
+    int r = build_ht_lds(c, (const J2kBlock *)blocks, nblocks, bases, nullptr, &tmp.lds);
     if (r < 0) return r;
     DevBuf db, dby, dc, ds;
     if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
@@ -887,7 +1025,6 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
     if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
     db.release(); dby.release(); dc.release(); ds.release();
-    tmp.plan = nullptr;
     if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_ht_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
     return 0;
 }

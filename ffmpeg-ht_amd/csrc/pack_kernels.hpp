@@ -23,20 +23,21 @@ struct PackComp {
     int32_t pix_step, pix_off;
 };
 
-struct PackTile {
-    PackComp c[4];
-    int32_t ncomp;
-    int32_t mct;             /* components 0..2 go through the inverse MCT of c[0].transform */
-    int32_t out_bytes;       /* 1: write_frame_8, 2: write_frame_16 */
-    int32_t precision;       /* write_frame's `precision` argument */
-    int32_t maxw, maxh;      /* largest component extent: the launch grid */
-};
-
 struct OutPlanes {
     uint8_t *ptr[4];
     int32_t  linesize[4];    /* bytes */
     int32_t  width[4];       /* pixels */
     int32_t  height[4];
+};
+
+struct PackTile {
+    PackComp c[4];
+    OutPlanes out;           /* the frame this tile belongs to */
+    int32_t ncomp;
+    int32_t mct;             /* components 0..2 go through the inverse MCT of c[0].transform */
+    int32_t out_bytes;       /* 1: write_frame_8, 2: write_frame_16 */
+    int32_t precision;       /* write_frame's `precision` argument */
+    int32_t maxw, maxh;      /* largest component extent: the launch grid */
 };
 
 __device__ __forceinline__ void pack_store(const OutPlanes &O, const PackTile &T, const PackComp &C,
@@ -54,9 +55,10 @@ __device__ __forceinline__ void pack_store(const OutPlanes &O, const PackTile &T
 }
 
 __global__ void __launch_bounds__(256)
-k_mct_pack(const PackTile *__restrict__ tiles, OutPlanes O)
+k_mct_pack(const PackTile *__restrict__ tiles)
 {
     const PackTile T = tiles[blockIdx.z];
+    const OutPlanes &O = T.out;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= T.maxw || y >= T.maxh) return;
     int first_plain = 0;

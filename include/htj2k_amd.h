@@ -133,6 +133,17 @@ typedef struct htj2k_job htj2k_job;  /* one parsed frame: descriptors + device b
 
 /* host: markers + Tier-2 -> per-codeblock descriptor table (no device work) */
 int  htj2k_job_parse(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size, htj2k_job **job);
+/* same for a batch of independent frames (the reference's frame-thread axis,
+ * libavcodec/pthread_frame.c:856-889): the descriptor tables are concatenated so that each
+ * device stage of the whole batch is ONE launch */
+int  htj2k_job_parse_batch(htj2k_ctx *ctx, const uint8_t *const *pkts, const int *pkt_sizes, int nframes,
+                           htj2k_job **job);
+int  htj2k_job_num_frames(const htj2k_job *job);
+int  htj2k_job_frame_info(const htj2k_job *job, int frame, htj2k_info *info);
+int  htj2k_job_download_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
+/* per-launch device time (ms) and algorithmic bytes of the IDWT kernels of the last run;
+ * returns the number of launches */
+int  htj2k_job_idwt_launches(htj2k_ctx *ctx, htj2k_job *job, float *ms, double *bytes, int cap);
 /* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
 int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
 /* device: HT block decode + dequant -> IDWT -> MCT/level shift/clip/pack (async) */

@@ -1,0 +1,300 @@
+"""GPU parity tests proper: everything goes through the C ABI (libhtj2k_amd.so) on a real
+MI355X and is compared with the CPU oracle on the same inputs.
+Bars: bit-exact for every integer path (5/3, 9/7 fixed point, HT block decode, MCT,
+pack); for the 9/7 float path the coefficient planes must be within 1 ULP and the final
+pixels identical (in practice both are bit-identical: same operation order, no FMA)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import streams
+import vecgen
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import ffmpeg_ht_amd as m
+    d = m.Decoder()
+    assert d.device_name().startswith("gfx950"), d.device_name()
+    yield d
+    d.close()
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return int(np.abs(ai - bi).max()) if a.size else 0
+
+
+KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[k["name"] for k in KATS])
+def test_kats_on_gpu(dec, kat):
+    info, planes, consumed, st = dec.decode(bytes.fromhex(kat["hex"]))
+    assert oracle.framecrc(planes) == int(kat["framecrc"], 16)
+    assert st.n_block_errors == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["idwt_generic", "idwt_tile"])
+@pytest.mark.parametrize("name", sorted(streams.CASES))
+def test_frames_match_oracle(dec, orc, name, mode):
+    data, kw = streams.get(name)
+    dec.set_int("idwt_mode", mode)
+    dec.set_int("bitexact", kw.get("bitexact", 0))
+    dec.set_int("reduction_factor", kw.get("reduction_factor", 0))
+    try:
+        info_o, planes_o, consumed_o = orc.decode(data, **kw)
+        info, planes, consumed, st = dec.decode(data)
+    finally:
+        dec.set_int("bitexact", 0)
+        dec.set_int("reduction_factor", 0)
+        dec.set_int("idwt_mode", 1)
+    assert (info.width, info.height, info.pix_fmt, info.bits_per_raw_sample) == \
+           (info_o.width, info_o.height, info_o.pix_fmt, info_o.bits_per_raw_sample)
+    assert consumed == consumed_o
+    assert st.n_block_errors == orc.block_errors() == 0
+    for a, b in zip(planes, planes_o):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["gray_l5_cb64", "rgb_mct", "gray_97_q2", "yuv422p12_97", "gray_3passes",
+                                  "gray_97_bitexact", "placeholder_2_3p", "gray_l3_cb256x16", "gray_l2_cb4x1024"])
+def test_stage_planes_match_oracle(dec, orc, name):
+    """coefficient planes after HT decode + dequantisation, and after the IDWT"""
+    data, kw = streams.get(name)
+    dec.set_int("bitexact", kw.get("bitexact", 0))
+    try:
+        orc.decode_blocks(data, **kw)
+        job = dec.job().parse(data).upload().run(1).wait()
+        ntc = job.num_tilecomps()
+        assert ntc == orc.num_tilecomps()
+        for tc in range(ntc):
+            a, b = job.plane(tc), orc.plane(tc)
+            assert a.dtype == b.dtype
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantised plane %d" % tc
+        orc.idwt()
+        for mode in (0, 1):
+            dec.set_int("idwt_mode", mode)
+            job.run(1).run(2).wait()
+            for tc in range(ntc):
+                a, b = job.plane(tc), orc.plane(tc)
+                if a.dtype == np.float32:
+                    assert _ulp_diff(a, b) <= 1            # north-star tolerance for 9/7 float
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "idwt plane %d mode %d" % (tc, mode)
+        job.free()
+    finally:
+        dec.set_int("bitexact", 0)
+        dec.set_int("idwt_mode", 1)
+
+
+def test_idwt_random_borders(dec):
+    """the reference's own DWT unit test shape (libavcodec/tests/jpeg2000dwt.c): random
+    borders incl. odd origins, 1..3 sample lines, levels deeper than the size allows"""
+    rng = np.random.default_rng(1234)
+    cases = [([[151, 170], [140, 183]], 15), ([[1, 4], [1, 3]], 2), ([[5, 6], [3, 20]], 2), ([[0, 1], [0, 1]], 3),
+             ([[1, 2], [1, 2]], 1), ([[0, 2], [0, 2]], 1), ([[3, 6], [2, 4]], 4), ([[0, 257], [1, 130]], 6)]
+    for _ in range(24):
+        x0, y0 = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        cases.append(([[x0, x0 + int(rng.integers(1, 260))], [y0, y0 + int(rng.integers(1, 200))]], int(rng.integers(1, 12))))
+    for border, lev in cases:
+        w, h = border[0][1] - border[0][0], border[1][1] - border[1][0]
+        for typ in (1, 0, 2):
+            if typ == 0:
+                p = (rng.standard_normal((h, w)) * 300).astype(np.float32)
+            else:
+                p = rng.integers(-3000, 3000, (h, w)).astype(np.int32) * (256 if typ == 2 else 1)
+            want = oracle.idwt(p, border, lev, typ)
+            for mode in (0, 1):
+                dec.set_int("idwt_mode", mode)
+                got = dec.idwt(p, border, lev, typ)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (border, lev, typ, mode)
+    dec.set_int("idwt_mode", 1)
+
+
+def test_idwt_53_wraparound(dec):
+    """unsigned wrap-around adds / arithmetic shifts of sr_1d53 (jpeg2000dwt.c:321-324)"""
+    rng = np.random.default_rng(5)
+    p = rng.integers(-2**31, 2**31 - 1, (70, 90), dtype=np.int64).astype(np.int32)
+    border = [[1, 91], [0, 70]]
+    want = oracle.idwt(p, border, 3, 1)
+    for mode in (0, 1):
+        dec.set_int("idwt_mode", mode)
+        assert np.array_equal(dec.idwt(p, border, 3, 1), want)
+    dec.set_int("idwt_mode", 1)
+
+
+def test_mct_kernels(dec):
+    """Jpeg2000DSPContext.mct_decode[] (checkasm jpeg2000dsp: rct_int memcmp, ict_float)"""
+    rng = np.random.default_rng(9)
+    n = 512 * 37 + 5
+    ints = [rng.integers(-2**20, 2**20, n).astype(np.int32) for _ in range(3)]
+    for typ in (1, 2):
+        want = oracle.mct(typ, *ints)
+        got = dec.mct(typ, *ints)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    fl = [(rng.standard_normal(n) * 500).astype(np.float32) for _ in range(3)]
+    want = oracle.mct(0, *fl)
+    got = dec.mct(0, *fl)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _block_case(rng, w, h, passes, amp, causal=False, M_b=None, density=1.0):
+    vals = rng.integers(-amp, amp + 1, (h, w))
+    if density < 1.0:
+        vals = np.where(rng.random((h, w)) < density, vals, 0)
+    data, lcup, lref, maxU = vecgen.encode_block(vals, passes, causal)
+    p = 1 if passes > 1 else 0
+    M_b = M_b or max(maxU + p, 1) + 1
+    return data, lcup, lref, passes, M_b - 1 - p, M_b, causal
+
+
+def test_ht_block_decoder_unit(dec):
+    """ff_jpeg2000_decode_htj2k + dequantization_int on raw cleanup/refinement segments:
+    block shapes incl. odd sizes, 1-wide, 1024x4, sparse and dense, every pass count"""
+    import ffmpeg_ht_amd as m
+    rng = np.random.default_rng(77)
+    shapes = [(64, 64), (32, 32), (63, 61), (1, 1), (2, 2), (3, 5), (1, 40), (40, 1), (1024, 4), (4, 1024),
+              (128, 32), (17, 200), (64, 3)]
+    descs, pool, expect, off, soff = [], b"", [], 0, 0
+    for (w, h) in shapes:
+        for passes in (1, 2, 3):
+            for amp, density in ((1, 0.05), (3, 0.5), (200, 1.0), (30000, 1.0)):
+                data, lcup, lref, npasses, zbp, M_b, causal = _block_case(rng, w, h, passes, amp, causal=(passes == 3 and w % 2 == 0),
+                                                                          density=density)
+                ret, t1 = oracle.ht_decode_block(data, lcup, lref, npasses, zbp, w, h, M_b, vsc=causal)
+                assert ret == 1
+                want = np.zeros((h, w), dtype=np.int32)
+                oracle.lib().orc_dequant_int(t1.ctypes.data, w, want.ctypes.data, w, w, h, M_b, 32768)
+                d = m.BlockDesc()
+                d.data_off, d.plane_off, d.lcup, d.lref, d.w, d.h, d.stride = off, soff, lcup, lref, w, h, w
+                d.npasses, d.zbp, d.M_b, d.flags, d.roi_shift, d.f_step, d.i_step = npasses, zbp, M_b, (8 if causal else 0) | 1, 0, 1.0, 32768
+                descs.append(d)
+                padded = data + b"\0" * ((-len(data)) % 16)
+                pool += padded
+                off += len(padded)
+                expect.append((soff, want))
+                soff += w * h
+    got, status = dec.ht_blocks(descs, pool, soff)
+    assert not status.any()
+    for (o, want) in expect:
+        assert np.array_equal(got[o:o + want.size].reshape(want.shape), want)
+
+
+def test_ht_block_errors_zero_the_block(dec):
+    """Lcup < 2, bad Scup, exponent bound above maxbp (jpeg2000htdec.c:1252,1268,715)"""
+    import ffmpeg_ht_amd as m
+    rng = np.random.default_rng(3)
+    vals = rng.integers(-200, 201, (32, 32))
+    data, lcup, lref, maxU = vecgen.encode_block(vals, 1)
+    cases = []
+    cases.append((data, 1, 0, 1, 9, 10))                       # Lcup < 2
+    bad = bytearray(data); bad[lcup - 1] = 0xFF                 # Scup > Lcup
+    cases.append((bytes(bad), lcup, 0, 1, 9, 10))
+    cases.append((data, lcup, 0, 1, 2, 3))                     # zbp too small for the coded magnitudes: U > maxbp
+    descs, pool, off = [], b"", 0
+    for i, (dat, lc, lr, npass, zbp, M_b) in enumerate(cases):
+        ret, _ = oracle.ht_decode_block(dat, lc, lr, npass, zbp, 32, 32, M_b)
+        assert ret < 0
+        d = m.BlockDesc()
+        d.data_off, d.plane_off, d.lcup, d.lref, d.w, d.h, d.stride = off, i * 1024, lc, lr, 32, 32, 32
+        d.npasses, d.zbp, d.M_b, d.flags, d.f_step, d.i_step = npass, zbp, M_b, 1, 1.0, 32768
+        descs.append(d)
+        padded = dat + b"\0" * ((-len(dat)) % 16)
+        pool += padded
+        off += len(padded)
+    got, status = dec.ht_blocks(descs, pool, 1024 * len(cases))
+    assert status.all()
+    assert not got.any()
+
+
+def test_corrupt_frame_block_is_zeroed(dec, orc):
+    data = bytearray(vecgen.encode(streams._img(64, 64, 1, 8, 3), nlevels=0))
+    data[-3] = 0xFF
+    info_o, planes_o, _ = orc.decode(bytes(data))
+    info, planes, _, st = dec.decode(bytes(data))
+    assert st.n_block_errors == 1 == orc.block_errors()
+    assert np.array_equal(planes[0], planes_o[0])
+
+
+def test_truncated_and_garbage_streams_do_not_fault(dec, orc):
+    """frame-fatal errors come back as the reference's AVERROR codes; nothing hangs or faults"""
+    import ffmpeg_ht_amd as m
+    data, _ = streams.get("rgb_mct")
+    for cut in (10, 60, 200, len(data) // 3, len(data) - 7):
+        try:
+            orc.decode(data[:cut])
+            code_o = 0
+        except oracle.DecodeError as e:
+            code_o = e.code
+        try:
+            dec.decode(data[:cut])
+            code = 0
+        except m.Htj2kError as e:
+            code = e.code
+        assert code == code_o
+    # bit flips inside the body: both decoders must agree on a frame (blocks may be rejected)
+    rng = np.random.default_rng(11)
+    for _ in range(6):
+        bad = bytearray(data)
+        for pos in rng.integers(300, len(bad) - 2, 8):
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            info_o, planes_o, _ = orc.decode(bytes(bad))
+        except oracle.DecodeError as e:
+            with pytest.raises(m.Htj2kError):
+                dec.decode(bytes(bad))
+            continue
+        info, planes, _, st = dec.decode(bytes(bad))      # must return; pixel parity on garbage is not required
+        assert planes[0].shape == planes_o[0].shape
+
+
+def test_linesize_padding_is_respected(dec, orc):
+    data, _ = streams.get("rgb_mct")
+    info_o, planes_o, _ = orc.decode(data)
+    info, planes, _, _ = dec.decode(data, align=64)
+    assert np.array_equal(planes[0], planes_o[0])
+
+
+def test_full_size_4k_properties(dec, orc):
+    """BASELINE config 2 at full size (3840x2160 RGB 8-bit, 5/3 + RCT, 5 levels, 64x64):
+    lossless round trip on the GPU, and a checksum of the frame against the oracle."""
+    img = vecgen.synth_image(3840, 2160, 3, seed=2)
+    data = vecgen.encode(img, mct=1)
+    info, planes, _, st = dec.decode(data)
+    assert st.n_codeblocks == 6321 and st.n_block_errors == 0
+    got = planes[0].reshape(2160, 3840, 3)
+    assert np.array_equal(got, np.stack(img, -1))
+    info_o, planes_o, _ = orc.decode(data)
+    assert oracle.framecrc(planes) == oracle.framecrc(planes_o)
+
+
+def test_full_size_4k_422_irreversible(dec, orc):
+    """BASELINE config 3: 4K 12-bit 4:2:2 9/7, 32x32 codeblocks (16 473 blocks)"""
+    img = vecgen.synth_image(3840, 2160, 3, depth=12, seed=3, noise=30, dx=[1, 2, 2], dy=[1, 1, 1])
+    data = vecgen.encode(img, depth=12, dx=[1, 2, 2], dy=[1, 1, 1], transform=0, qstep=1.0, cb=(5, 5), width=3840, height=2160)
+    info, planes, _, st = dec.decode(data)
+    assert st.n_codeblocks == 16473 and st.n_block_errors == 0
+    info_o, planes_o, _ = orc.decode(data)
+    for a, b in zip(planes, planes_o):
+        assert np.array_equal(a, b)
+
+
+def test_full_size_8k_16bit(dec, orc):
+    """BASELINE config 4: 7680x4320 16-bit gray, 5/3, 6 levels (8 227 blocks, IDWT stress)"""
+    img = vecgen.synth_image(7680, 4320, 1, depth=16, seed=4, noise=300)
+    data = vecgen.encode(img, depth=16, nlevels=6)
+    info, planes, _, st = dec.decode(data)
+    assert st.n_codeblocks == 8227 and st.n_block_errors == 0
+    assert np.array_equal(planes[0], img[0])
