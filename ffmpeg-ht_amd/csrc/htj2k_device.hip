@@ -657,7 +657,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
     }
     if (mask & 4) {
         if (j->npack && j->pack_maxw > 0 && j->pack_maxh > 0) {
-            dim3 g((j->pack_maxw + 255) / 256, j->pack_maxh, j->npack);
+            dim3 g((j->pack_maxw + 1023) / 1024, j->pack_maxh, j->npack);
             hipLaunchKernelGGL(k_mct_pack, g, dim3(256), 0, j->stream,
                                (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off));
             HIP_TRY(c, hipGetLastError());

@@ -40,62 +40,135 @@ struct PackTile {
     int32_t maxw, maxh;      /* largest component extent: the launch grid */
 };
 
-__device__ __forceinline__ void pack_store(const OutPlanes &O, const PackTile &T, const PackComp &C,
-                                           int x, int y, int val)
+/* One thread = 4 horizontally adjacent sample positions of every component of a tile:
+ * 16-byte plane loads, the inverse MCT in registers, and the packed / planar output row
+ * assembled into whole dwords (rgb24: 12 bytes per thread) instead of byte stores. */
+__device__ __forceinline__ int pack_value(const PackTile &T, const PackComp &C, int val)
 {
     val += 1 << (C.cbps - 1);
     val = min(max(val, 0), (1 << C.cbps) - 1);            /* av_clip */
-    val <<= (T.precision - C.cbps);
-    const int px = C.out_x + x, py = C.out_y + y;
-    if (px < 0 || py < 0 || px >= O.width[C.out_plane] || py >= O.height[C.out_plane])
-        return;                                            /* never write outside the caller's picture */
-    uint8_t *line = O.ptr[C.out_plane] + (size_t)py * O.linesize[C.out_plane];
-    if (T.out_bytes == 1) line[px * C.pix_step + C.pix_off] = (uint8_t)val;
-    else ((uint16_t *)line)[px * C.pix_step + C.pix_off] = (uint16_t)val;
+    return val << (T.precision - C.cbps);
 }
 
 __global__ void __launch_bounds__(256)
 k_mct_pack(const PackTile *__restrict__ tiles)
 {
-    const PackTile T = tiles[blockIdx.z];
+    const PackTile &T = tiles[blockIdx.z];
     const OutPlanes &O = T.out;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= T.maxw || y >= T.maxh) return;
-    int first_plain = 0;
-    if (T.mct) {
-        first_plain = 3;
-        const PackComp &C0 = T.c[0];
-        if (x < C0.w && y < C0.h) {
-            const size_t o = (size_t)y * C0.w + x;
-            const uint32_t s0 = T.c[0].src[o], s1 = T.c[1].src[o], s2 = T.c[2].src[o];
-            int v0, v1, v2;
-            if (C0.transform == J2K_DWT53) {                /* rct_int, jpeg2000dsp.c:78-91 */
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= T.maxw || y >= T.maxh) return;
+    const int ncomp = T.ncomp;
+    int v[4][4];
+    int cnt[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cnt[c] = 0;
+        if (c >= ncomp) continue;
+        const PackComp &C = T.c[c];
+        if (x0 >= C.w || y >= C.h) continue;
+        const int n = min(4, C.w - x0);
+        cnt[c] = n;
+        const uint32_t *p = C.src + (size_t)y * C.w + x0;
+        uint32_t r[4] = { 0, 0, 0, 0 };
+        if (n == 4 && ((((uintptr_t)p) & 15) == 0)) {
+            const uint4 q = *(const uint4 *)p;
+            r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+        } else {
+            for (int i = 0; i < n; i++) r[i] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[c][i] = (int)r[i];
+    }
+    if (T.mct && cnt[0]) {
+        const int tr = T.c[0].transform;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t s0 = (uint32_t)v[0][i], s1 = (uint32_t)v[1][i], s2 = (uint32_t)v[2][i];
+            if (tr == J2K_DWT53) {                          /* rct_int, jpeg2000dsp.c:78-91 */
                 const uint32_t i1 = s0 - (uint32_t)((int32_t)(s2 + s1) >> 2);
-                v0 = (int32_t)(i1 + s2); v1 = (int32_t)i1; v2 = (int32_t)(i1 + s1);
-            } else if (C0.transform == J2K_DWT97) {         /* ict_float, :43-59 */
+                v[0][i] = (int32_t)(i1 + s2); v[1][i] = (int32_t)i1; v[2][i] = (int32_t)(i1 + s1);
+            } else if (tr == J2K_DWT97) {                   /* ict_float, :43-59, then lrintf (jpeg2000dec.c:2340) */
                 const float f0 = __uint_as_float(s0), f1 = __uint_as_float(s1), f2 = __uint_as_float(s2);
                 const float i0f = f0 + (1.402f * f2);
                 const float i1f = f0 - (0.34413f * f1) - (0.71414f * f2);
                 const float i2f = f0 + (1.772f * f1);
-                v0 = __float2int_rn(i0f); v1 = __float2int_rn(i1f); v2 = __float2int_rn(i2f);   /* lrintf */
+                v[0][i] = __float2int_rn(i0f); v[1][i] = __float2int_rn(i1f); v[2][i] = __float2int_rn(i2f);
             } else {                                        /* ict_int, :61-76 */
                 const int32_t a0 = (int32_t)s0, a1 = (int32_t)s1, a2 = (int32_t)s2;
-                v0 = a0 + a2 + ((int)((26345U * (uint32_t)a2) + (1 << 15)) >> 16);
-                v1 = a0 - ((int)((22553U * (uint32_t)a1) + (1 << 15)) >> 16)
-                        - ((int)((46802U * (uint32_t)a2) + (1 << 15)) >> 16);
-                v2 = a0 + (2 * a1) + ((int)((-14942U * (uint32_t)a1) + (1 << 15)) >> 16);
+                v[0][i] = a0 + a2 + ((int)((26345U * (uint32_t)a2) + (1 << 15)) >> 16);
+                v[1][i] = a0 - ((int)((22553U * (uint32_t)a1) + (1 << 15)) >> 16)
+                             - ((int)((46802U * (uint32_t)a2) + (1 << 15)) >> 16);
+                v[2][i] = a0 + (2 * a1) + ((int)((-14942U * (uint32_t)a1) + (1 << 15)) >> 16);
             }
-            pack_store(O, T, T.c[0], x, y, v0);
-            pack_store(O, T, T.c[1], x, y, v1);
-            pack_store(O, T, T.c[2], x, y, v2);
         }
     }
-    for (int c = first_plain; c < T.ncomp; c++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (!cnt[c]) continue;
         const PackComp &C = T.c[c];
-        if (x >= C.w || y >= C.h) continue;
-        const uint32_t s = C.src[(size_t)y * C.w + x];
-        const int v = C.transform == J2K_DWT97 ? __float2int_rn(__uint_as_float(s)) : (int32_t)s;
-        pack_store(O, T, C, x, y, v);
+        const bool fl = C.transform == J2K_DWT97 && !(T.mct && c < 3);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int raw = fl ? __float2int_rn(__int_as_float(v[c][i])) : v[c][i];
+            v[c][i] = pack_value(T, C, raw);
+        }
+    }
+    /* ---- stores ---- */
+    const PackComp &C0 = T.c[0];
+    const bool packed = C0.pix_step > 1;
+    if (packed) {
+        /* all components share plane, geometry and pixel pitch = ncomp samples */
+        const int n = cnt[0], step = C0.pix_step, pl = C0.out_plane;
+        const int px = C0.out_x + x0, py = C0.out_y + y;
+        if (py < 0 || py >= O.height[pl] || px < 0) return;
+        const int nvalid = min(n, O.width[pl] - px);
+        if (nvalid <= 0) return;
+        uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)px * step * T.out_bytes;
+        const int nbytes = nvalid * step * T.out_bytes;
+        uint32_t wbuf[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };       /* up to 4 px * 4 comps * 2 bytes */
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (c >= step) continue;
+                const int comp = c;                             /* pix_off == component index for packed formats */
+                const int val = (comp < ncomp) ? v[comp][i] : 0;
+                const int k = i * step + T.c[comp < ncomp ? comp : 0].pix_off;
+                if (T.out_bytes == 1) wbuf[k >> 2] |= (uint32_t)(val & 0xFF) << ((k & 3) * 8);
+                else wbuf[k >> 1] |= (uint32_t)(val & 0xFFFF) << ((k & 1) * 16);
+            }
+        if ((((uintptr_t)dst) & 3) == 0 && (nbytes & 3) == 0) {
+            for (int k = 0; k < (nbytes >> 2); k++) ((uint32_t *)dst)[k] = wbuf[k];
+        } else {
+            for (int k = 0; k < nbytes; k++) dst[k] = (uint8_t)(wbuf[k >> 2] >> ((k & 3) * 8));
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (!cnt[c]) continue;
+            const PackComp &C = T.c[c];
+            const int pl = C.out_plane;
+            const int px = C.out_x + x0, py = C.out_y + y;
+            if (py < 0 || py >= O.height[pl] || px < 0) continue;
+            const int nvalid = min(cnt[c], O.width[pl] - px);
+            if (nvalid <= 0) continue;
+            uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)(px * C.pix_step + C.pix_off) * T.out_bytes;
+            if (T.out_bytes == 1) {
+                if (nvalid == 4 && (((uintptr_t)dst) & 3) == 0)
+                    *(uint32_t *)dst = (uint32_t)(v[c][0] & 0xFF) | ((uint32_t)(v[c][1] & 0xFF) << 8) |
+                                       ((uint32_t)(v[c][2] & 0xFF) << 16) | ((uint32_t)(v[c][3] & 0xFF) << 24);
+                else
+                    for (int i = 0; i < nvalid; i++) dst[i] = (uint8_t)v[c][i];
+            } else {
+                if (nvalid == 4 && (((uintptr_t)dst) & 7) == 0) {
+                    uint2 q;
+                    q.x = (uint32_t)(v[c][0] & 0xFFFF) | ((uint32_t)(v[c][1] & 0xFFFF) << 16);
+                    q.y = (uint32_t)(v[c][2] & 0xFFFF) | ((uint32_t)(v[c][3] & 0xFFFF) << 16);
+                    *(uint2 *)dst = q;
+                } else
+                    for (int i = 0; i < nvalid; i++) ((uint16_t *)dst)[i] = (uint16_t)v[c][i];
+            }
+        }
     }
 }
 

@@ -3,6 +3,7 @@ MI355X and is compared with the CPU oracle on the same inputs.
 Bars: bit-exact for every integer path (5/3, 9/7 fixed point, HT block decode, MCT,
 pack); for the 9/7 float path the coefficient planes must be within 1 ULP and the final
 pixels identical (in practice both are bit-identical: same operation order, no FMA)."""
+import ctypes
 import json
 import os
 
@@ -176,7 +177,7 @@ def test_ht_block_decoder_unit(dec):
                 ret, t1 = oracle.ht_decode_block(data, lcup, lref, npasses, zbp, w, h, M_b, vsc=causal)
                 assert ret == 1
                 want = np.zeros((h, w), dtype=np.int32)
-                oracle.lib().orc_dequant_int(t1.ctypes.data, w, want.ctypes.data, w, w, h, M_b, 32768)
+                oracle.lib().orc_dequant_int(t1.ctypes.data_as(ctypes.c_void_p), w, want.ctypes.data_as(ctypes.c_void_p), w, w, h, M_b, 32768)
                 d = m.BlockDesc()
                 d.data_off, d.plane_off, d.lcup, d.lref, d.w, d.h, d.stride = off, soff, lcup, lref, w, h, w
                 d.npasses, d.zbp, d.M_b, d.flags, d.roi_shift, d.f_step, d.i_step = npasses, zbp, M_b, (8 if causal else 0) | 1, 0, 1.0, 32768
