@@ -162,10 +162,16 @@ __device__ __forceinline__ void ht_zero_window(uint32_t *dst, int w, int h, int 
 
 __device__ __forceinline__ int bm_get(const uint32_t *bm, int idx) { return (bm[idx >> 5] >> (idx & 31)) & 1; }
 
+/* EXTERNAL_VLC = false: the whole block in this kernel (stage 1 on lane 0).
+ * EXTERNAL_VLC = true : stage 1 was done by k_ht_vlc (one LANE per codeblock, 64 serial decodes
+ *                       per wavefront); the packed quad symbols come from `qsym` (qoff[b] is the
+ *                       index of block b's first quad) and only MagSgn/refinement run here. */
+template <bool EXTERNAL_VLC>
 __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
-            int *__restrict__ status, HtLds L)
+            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
+            const uint32_t *__restrict__ ms_u)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -200,8 +206,8 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     }
     if (!err && maxbp >= 32) err = HT_ERR_INVALID;     /* :617 */
     /* LDS capacity is sized by the host from the same fields; never index past it */
-    if (!err && ((Pcup * 8 + 31) / 32 + 2 > L.ms_words || (Scup * 8 + 31) / 32 + 2 > L.vlc_words ||
-                 Scup > L.suf_bytes || (uint32_t)qw > L.max_qw))
+    if (!err && ((Pcup * 8 + 31) / 32 + 2 > L.ms_words || (uint32_t)qw > L.max_qw ||
+                 (!EXTERNAL_VLC && ((Scup * 8 + 31) / 32 + 2 > L.vlc_words || Scup > L.suf_bytes))))
         err = HT_ERR_INVALID;
     if (err) {
         ht_zero_window(dst, w, h, stride, lane);
@@ -220,18 +226,24 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     const uint32_t nms = (Pcup * 8 + 31) / 32 + 2, nvl = (Scup * 8 + 31) / 32 + 2;
 
     /* ---- stage 0: tables, zero, un-stuff ---- */
-    for (int i = lane; i < 1024; i += 64)
-        ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+    if (!EXTERNAL_VLC) {
+        for (int i = lane; i < 1024; i += 64)
+            ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+        for (uint32_t i = lane; i < nvl; i += 64) vlcw[i] = 0;
+    }
     for (uint32_t i = lane; i < nms; i += 64) ms[i] = 0;
-    for (uint32_t i = lane; i < nvl; i += 64) vlcw[i] = 0;
     for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
     for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
     if (z_blk > 1)
         for (uint32_t i = lane; i < 4 * L.bm_words; i += 64) bm[i] = 0;
     __syncthreads();
 
-    uint32_t ms_total;
-    {   /* MagSgn: forward, a byte after 0xFF advances 7 bits but ORs all 8 (jpeg2000htdec.c:207-221) */
+    uint32_t ms_total = 0;
+    if (EXTERNAL_VLC) {
+        /* un-stuffed (and ones-padded) by k_ht_unstuff: a plain coalesced copy */
+        const uint32_t *src = ms_u + (b.data_off >> 2);
+        for (uint32_t i = lane; i < nms; i += 64) ms[i] = src[i];
+    } else {   /* MagSgn: forward, a byte after 0xFF advances 7 bits but ORs all 8 (jpeg2000htdec.c:207-221) */
         uint32_t base = 0;
         for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -249,7 +261,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         }
         ms_total = base;
     }
-    {   /* VLC: backward from Dcup[Lcup-2]; Dcup[Lcup-1] counts as 0xFF and the low nibble of
+    if (!EXTERNAL_VLC) {   /* VLC: backward from Dcup[Lcup-2]; Dcup[Lcup-1] counts as 0xFF and the low nibble of
          * Dcup[Lcup-2] as 0xF (:1277-1278); a byte with 7 LSBs set below a byte > 0x8F loses its MSB */
         uint32_t base = 0;
         const uint32_t nv = Scup - 1;                 /* bytes Lcup-2 .. Pcup */
@@ -274,14 +286,14 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             base += __shfl(incl, 63, 64);
         }
     }
-    for (uint32_t i = lane; i < Scup; i += 64) {       /* MEL reads the (patched) suffix bytes */
+    for (uint32_t i = lane; !EXTERNAL_VLC && i < Scup; i += 64) {       /* MEL reads the (patched) suffix bytes */
         uint32_t v = D[Pcup + i];
         if (Pcup + i == Lcup - 1) v = 0xFF;
         else if (Pcup + i == Lcup - 2) v |= 0x0F;
         suf[i] = (uint8_t)v;
     }
     __syncthreads();
-    for (uint32_t i = lane; i < nms; i += 64) {        /* past the end the MagSgn stream is all ones */
+    for (uint32_t i = lane; !EXTERNAL_VLC && i < nms; i += 64) {        /* past the end the MagSgn stream is all ones */
         if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
         else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
     }
@@ -291,7 +303,8 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     S.vbuf = 0; S.vbits = 0; S.vword = 0; S.vlc = vlcw; S.vlc_words = nvl;
     S.suf = suf; S.mel_pos = 0; S.mel_len = Scup; S.mel_tmp = 0; S.mel_bits = 0;
     S.mel_k = 0; S.mel_run = 0; S.mel_one = 0;
-    if (lane == 0) S.vdrop(0), S.vfill(), S.vdrop(4);   /* jpeg2000_init_vlc drops the Scup nibble, :283-295 */
+    if (!EXTERNAL_VLC && lane == 0) S.vdrop(0), S.vfill(), S.vdrop(4);   /* jpeg2000_init_vlc drops the Scup nibble, :283-295 */
+    const uint32_t *qglob = EXTERNAL_VLC ? qsym + qoff[blockIdx.x] : nullptr;
 
     float fscale = b.f_step;
     fscale /= (float)(1 << (31 - b.M_b));              /* jpeg2000dec.c:2104-2106 */
@@ -306,7 +319,9 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         uint8_t *Ecur = Earr + (row & 1) * Estride + 4, *Eprev = Earr + ((row & 1) ^ 1) * Estride + 4;
 
         /* ---- stage 1: serial quad-row decode on lane 0 ---- */
-        if (lane == 0) {
+        if (EXTERNAL_VLC) {
+            for (int q = lane; q < qw; q += 64) qcur[q] = qglob[row * qw + q];
+        } else if (lane == 0) {
             const uint16_t *table = tbl + (row ? 1024 : 0);
             int rho_left = 0;
             for (int qx = 0; qx < qw; qx += 2) {
@@ -546,6 +561,324 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                 }
                 dst[(size_t)y * stride + x] = ht_dequant(v, transform, M_b, roi_shift, fscale, i_step);
             }
+    }
+}
+
+
+/* ================================================================== split pipeline
+ * k_ht_unstuff  (wave per block)  removes the bit stuffing of all three byte streams of the
+ *               cleanup segment in parallel (per-byte bit counts, wave prefix sum, ds_or) and
+ *               writes them as plain bit arrays: MagSgn LSB-first padded with ones
+ *               (jpeg2000htdec.c:207-221), VLC LSB-first in read order padded with zeros
+ *               (:145-201, first 4 bits = the Scup nibble), MEL MSB-first padded with ones
+ *               (:429-440).
+ * k_ht_vlc      (LANE per block)  the serial MEL / CxtVLC / U-VLC chain (:632-973); 64 blocks
+ *               per wavefront.  With stuffing gone a refill is "append the next dword", a MEL
+ *               read is a shift, and the first-row / other-row / paired / unpaired U-VLC cases
+ *               are one branch-free sequence -- divergent lanes cost every path, so the loop
+ *               body is kept small rather than fast-pathed.
+ * k_ht_decode<true> (wave per block)  MagSgn + dequantisation + refinement passes.
+ * The host sorts the block table by size so that the 64 lanes of a k_ht_vlc wave run similar
+ * trip counts. */
+__global__ void __launch_bounds__(64)
+k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+             uint32_t *__restrict__ ms_u, uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u,
+             uint32_t lds_words)
+{
+    extern __shared__ __align__(16) uint32_t sw[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= nblocks) return;
+    const J2kBlock b = blocks[blockIdx.x];
+    if (b.npasses == 0 || b.lcup < 2) return;
+    const uint8_t *D = bytes + b.data_off;
+    const uint32_t Lcup = b.lcup;
+    const uint32_t Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+    if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
+    const uint32_t Pcup = Lcup - Scup;
+    const uint32_t nms = (Pcup * 8 + 31) / 32 + 2, nsw = (Scup * 8 + 31) / 32 + 2;
+    if (nms > lds_words || nsw > lds_words) return;      /* host sized the LDS from the same fields */
+    uint32_t *msO = ms_u + (b.data_off >> 2), *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
+
+    /* ---- MagSgn ---- */
+    for (uint32_t i = lane; i < nms; i += 64) sw[i] = 0;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool act = i < Pcup;
+        const uint32_t byte = act ? D[i] : 0;
+        const uint32_t prev = (act && i > 0) ? D[i - 1] : 0;
+        const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(nb, lane);
+        const uint32_t off = base + incl - nb;
+        if (act) {
+            atomicOr(&sw[off >> 5], byte << (off & 31));
+            if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], byte >> (32 - (off & 31)));
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nms; i += 64) {
+        uint32_t v = sw[i];
+        if (i * 32 >= base) v = 0xFFFFFFFFu;
+        else if (i * 32 + 32 > base) v |= 0xFFFFFFFFu << (base & 31);
+        msO[i] = v;
+    }
+    __syncthreads();
+
+    /* ---- VLC (backward) ---- */
+    for (uint32_t i = lane; i < nsw; i += 64) sw[i] = 0;
+    __syncthreads();
+    base = 0;
+    const uint32_t nv = Scup - 1;
+    for (uint32_t k0 = 0; k0 < nv; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const bool act = k < nv;
+        uint32_t v = 0, above = 0xFF;
+        if (act) {
+            const uint32_t j = Lcup - 2 - k;
+            v = D[j];
+            if (k == 0) v |= 0x0F;
+            else { above = D[j + 1]; if (k == 1) above |= 0x0F; }
+        }
+        const uint32_t nb = act ? ((above > 0x8F && (v & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+        v &= (1u << nb) - 1;
+        const uint32_t incl = wave_incl_scan_u32(nb, lane);
+        const uint32_t off = base + incl - nb;
+        if (act) {
+            atomicOr(&sw[off >> 5], v << (off & 31));
+            if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], v >> (32 - (off & 31)));
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nsw; i += 64) vlO[i] = sw[i];
+    __syncthreads();
+
+    /* ---- MEL (forward from Dcup[Pcup], MSB-first) ---- */
+    for (uint32_t i = lane; i < nsw; i += 64) sw[i] = 0;
+    __syncthreads();
+    base = 0;
+    for (uint32_t i0 = 0; i0 < Scup; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool act = i < Scup;
+        uint32_t v = 0, prev = 0;
+        if (act) {
+            const uint32_t a = Pcup + i;
+            v = D[a];
+            if (a == Lcup - 1) v = 0xFF; else if (a == Lcup - 2) v |= 0x0F;       /* modDcup, :1277-1278 */
+            if (i > 0) { prev = D[a - 1]; if (a - 1 == Lcup - 2) prev |= 0x0F; }
+        }
+        const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
+        v &= (1u << nb) - 1;
+        const uint32_t incl = wave_incl_scan_u32(nb, lane);
+        const uint32_t off = base + incl - nb;             /* stream position of the byte's first (top) bit */
+        if (act) {
+            const uint32_t sh = off & 31;                  /* place v's nb bits at [31-sh .. 31-sh-nb+1] */
+            if (sh + nb <= 32) atomicOr(&sw[off >> 5], v << (32 - sh - nb));
+            else {
+                const uint32_t spill = sh + nb - 32;
+                atomicOr(&sw[off >> 5], v >> spill);
+                atomicOr(&sw[(off >> 5) + 1], v << (32 - spill));
+            }
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nsw; i += 64) {            /* 0xFF bytes forever past the segment */
+        uint32_t v = sw[i];
+        if (i * 32 >= base) v = 0xFFFFFFFFu;
+        else if (i * 32 + 32 > base) v |= 0xFFFFFFFFu >> (base & 31);
+        meO[i] = v;
+    }
+}
+
+/* ---- k_ht_vlc: one lane per codeblock ----
+ * Bit positions instead of streaming buffers: the un-stuffed VLC and MEL streams are plain bit
+ * arrays, so a lane only tracks `vpos` / `mpos`.  A quad pair consumes at most 38 VLC bits
+ * (2 x 7 codeword + 2 x (3 + 5 + 4) U-VLC) and 18 MEL bits (3 symbols x (1 + 5)), hence the
+ * four VLC dwords / three MEL dwords that start at the word holding the CURRENT position also
+ * cover everything the NEXT pair can touch.  Each iteration therefore issues exactly one
+ * dwordx4 and one dwordx3 load for the next iteration and waits for them only at its end:
+ * no queues, no refill branches, no data-dependent control flow around memory. */
+struct Win128 { uint32_t w0, w1, w2, w3; uint32_t base; };   /* base = word index of w0 */
+
+__device__ __forceinline__ uint64_t vlc_window(const Win128 &W, uint32_t pos)
+{
+    /* 64 stream bits starting at bit `pos` (LSB-first); pos - 32*base is in [0, 70] */
+    const uint32_t off = pos - (W.base << 5);
+    const uint32_t k = off >> 5, sh = off & 31;
+    const uint32_t a = k == 0 ? W.w0 : (k == 1 ? W.w1 : W.w2);
+    const uint32_t b = k == 0 ? W.w1 : (k == 1 ? W.w2 : W.w3);
+    const uint32_t c = k == 0 ? W.w2 : (k == 1 ? W.w3 : 0u);
+    const uint64_t lo = ((uint64_t)b << 32) | a;
+    return sh ? ((lo >> sh) | ((uint64_t)c << (64 - sh))) : lo;
+}
+
+__device__ __forceinline__ uint32_t mel_window(const Win128 &W, uint32_t pos)
+{
+    /* 32 stream bits starting at bit `pos`, first bit in the MSB (words are MSB-first) */
+    const uint32_t off = pos - (W.base << 5);
+    const uint32_t k = off >> 5, sh = off & 31;
+    const uint32_t a = k == 0 ? W.w0 : W.w1;
+    const uint32_t b = k == 0 ? W.w1 : W.w2;
+    return sh ? ((a << sh) | (b >> (32 - sh))) : a;
+}
+
+/* jpeg2000_decode_mel_sym (jpeg2000htdec.c:462-495) on a 32-bit MSB-first window; `en` = false
+ * leaves everything untouched.  Returns the symbol; `m` is advanced past the consumed bits. */
+struct MelState { int k, run, one; };
+__device__ __forceinline__ int mel_sym(MelState &S, uint32_t &m, uint32_t &mused, bool en)
+{
+    const bool start = en && S.run == 0 && S.one == 0;
+    const int eval = (int)((0x5433222111000ull >> (4 * S.k)) & 0xF);
+    const uint32_t b = m >> 31;
+    const int r0 = eval ? (int)((m << 1) >> (32 - eval)) : 0;
+    const uint32_t used = start ? (b ? 1u : 1u + (uint32_t)eval) : 0u;
+    if (start) {
+        S.run = b ? (1 << eval) : r0;
+        S.k = b ? (S.k < 12 ? S.k + 1 : 12) : (S.k > 0 ? S.k - 1 : 0);
+        S.one = b ? 0 : 1;
+    }
+    m <<= used;
+    mused += used;
+    int ret = 0;
+    if (en) {
+        if (S.run > 0) S.run--;
+        else { S.one = 0; ret = 1; }
+    }
+    return ret;
+}
+
+__global__ void __launch_bounds__(64)
+k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+         const uint16_t *__restrict__ g_tables, uint32_t *__restrict__ qsym,
+         const uint32_t *__restrict__ qoff, uint32_t max_qw,
+         const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u, int dbg)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint16_t *tbl = (uint16_t *)smem;
+    /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
+     * dwords is odd so the 64 lanes hit distinct banks */
+    uint8_t *rho_rows = smem + 4096;
+    const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
+    const int lane = threadIdx.x;
+    const int bi = blockIdx.x * 64 + lane;
+    for (int i = lane; i < 1024; i += 64)
+        ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+    __syncthreads();
+
+    int qw = 0, qh = 0;
+    uint32_t doff = 0;
+    uint32_t *qout = qsym;
+    if (bi < nblocks) {
+        const J2kBlock b = blocks[bi];
+        bool ok = b.npasses != 0 && b.lcup >= 2;
+        if (ok) {
+            const uint8_t *D = bytes + b.data_off;
+            const uint32_t Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
+            ok = !(Scup < 2 || Scup > b.lcup || Scup > 4079);
+        }
+        if (ok && ((b.w + 1u) >> 1) <= max_qw) {
+            qw = (b.w + 1) >> 1;
+            qh = (b.h + 1) >> 1;
+            qout = qsym + qoff[bi];
+            doff = b.data_off >> 2;
+        }
+    }
+    const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
+    uint8_t *myrho = rho_rows + lane * pitch;
+    uint32_t vpos = 4, mpos = 0;                         /* the first 4 VLC bits are the Scup nibble (:283-295) */
+    MelState MS = { 0, 0, 0 };
+    Win128 VW = { 0, 0, 0, 0, 0 }, MW = { 0, 0, 0, 0, 0 };
+    if (qh > 0) {
+        VW.w0 = vsrc[0]; VW.w1 = vsrc[1]; VW.w2 = vsrc[2]; VW.w3 = vsrc[3];
+        MW.w0 = msrc[0]; MW.w1 = msrc[1]; MW.w2 = msrc[2];
+    }
+    int ctx_run = 0;
+    for (int row = 0; row < qh; row++) {
+        const uint16_t *table = tbl + (row ? 1024 : 0);
+        const bool row0 = row == 0;
+        int rho_left = 0, ral = 0;
+        int ra_next = row ? (int)myrho[0] : 0;           /* above quad 0 */
+        uint32_t *rowout = qout + (size_t)row * qw;
+        for (int qx = 0; qx < qw && !(dbg & 2); qx += 2) {
+            const bool pair = qx + 1 < qw;
+            /* loads for the NEXT iteration, based at the word of the current positions */
+            Win128 VN, MN;
+            VN.base = vpos >> 5; MN.base = mpos >> 5;
+            {
+                const uint32_t *pv = vsrc + VN.base, *pm = msrc + MN.base;
+                VN.w0 = pv[0]; VN.w1 = pv[1]; VN.w2 = pv[2]; VN.w3 = pv[3];
+                MN.w0 = pm[0]; MN.w1 = pm[1]; MN.w2 = pm[2]; MN.w3 = 0;
+            }
+            const uint64_t vwin = vlc_window(VW, vpos);
+            uint32_t m = mel_window(MW, mpos), mused = 0;
+            uint32_t a = (uint32_t)vwin, aused = 0;     /* the two codewords need <= 14 bits */
+            int rho[2], uoff[2], ek[2], e1[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool en = k == 0 || pair;
+                const int q = qx + k;
+                const int ra = ra_next;
+                const int rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
+                const int ctx = row0 ? ctx_run
+                                     : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
+                                        ((((ra >> 3) | (rar >> 1)) & 1) << 2));
+                const int msym = mel_sym(MS, m, mused, en && ctx == 0);
+                const bool dec = en && (ctx != 0 || msym != 0);
+                const uint32_t e = dec ? table[(ctx << 7) | (a & 0x7F)] : 0u;
+                const uint32_t len = (e >> 1) & 7;
+                a >>= len; aused += len;
+                uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; ek[k] = (e >> 8) & 0xF; e1[k] = (e >> 12) & 0xF;
+                if (en) {
+                    rho_left = rho[k];
+                    ral = ra;
+                    ra_next = rar;
+                    ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
+                }
+            }
+            /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) for both quads, branch-free, on a
+             * fresh 32-bit window (<= 24 bits): decode order pfx1 pfx2 sfx1 sfx2 ext1 ext2; first
+             * row with both offsets set: one MEL symbol, 1 => both u get +2, 0 and pfx1 > 2 => u2
+             * is a single bit + 1 */
+            uint32_t u32w = (uint32_t)(vwin >> aused), uused = 0;
+            const bool both = uoff[0] && uoff[1];
+            const int mel2 = mel_sym(MS, m, mused, row0 && both);
+            const uint32_t b1 = u32w & 7;
+            const int p1 = uoff[0] ? (int)((0x12131215u >> (4 * b1)) & 0xF) : 0;
+            uint32_t d = uoff[0] ? ((0x12131213u >> (4 * b1)) & 0xF) : 0u;
+            u32w >>= d; uused += d;
+            const bool special = row0 && both && !mel2 && p1 > 2;
+            const uint32_t b2 = u32w & 7;
+            const int p2 = (uoff[1] && !special) ? (int)((0x12131215u >> (4 * b2)) & 0xF) : 0;
+            d = special ? 1u : (uoff[1] ? ((0x12131213u >> (4 * b2)) & 0xF) : 0u);
+            u32w >>= d; uused += d;
+            const int one_bit = (int)(b2 & 1);
+            d = p1 < 3 ? 0u : (p1 == 3 ? 1u : 5u);
+            const int s1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+            d = p2 < 3 ? 0u : (p2 == 3 ? 1u : 5u);
+            const int s2 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+            d = s1 >= 28 ? 4u : 0u;
+            const int x1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+            d = s2 >= 28 ? 4u : 0u;
+            const int x2 = (int)(u32w & ((1u << d) - 1)); uused += d;
+            const int bias = (row0 && both && mel2) ? 2 : 0;
+            const int u1 = uoff[0] ? bias + p1 + s1 + 4 * x1 : 0;
+            const int u2 = special ? one_bit + 1 : (uoff[1] ? bias + p2 + s2 + 4 * x2 : 0);
+            vpos += aused + uused;
+            mpos += mused;
+            myrho[qx] = (uint8_t)rho[0];
+            if (pair) myrho[qx + 1] = (uint8_t)rho[1];
+            /* single wait point: next iteration's windows (loaded at the top) become current,
+             * then this pair's symbols are stored -- they have a whole iteration to drain */
+            VW = VN; MW = MN;
+            if (!(dbg & 1)) {
+                rowout[qx] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
+                if (pair)
+                    rowout[qx + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
+            }
+        }
     }
 }
 

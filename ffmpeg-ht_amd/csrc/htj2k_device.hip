@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -54,6 +55,7 @@ struct htj2k_ctx {
     J2kParser *probe_parser = nullptr;
     htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
     int idwt_mode = 1;                 /* 0 = generic two-pass kernels, 1 = fused LDS tile kernels */
+    int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
 };
 
@@ -88,7 +90,11 @@ struct htj2k_job {
     std::vector<hipEvent_t> lev_ev;    /* per-IDWT-launch brackets (roofline measurement) */
     int lev_ev_used = 0;
     std::vector<double> lev_bytes;     /* algorithmic bytes of each recorded launch */
-    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc;
+    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_msu, d_vlcu, d_melu;
+    std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
+    size_t nquads = 0;
+    HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
+    uint32_t max_qw = 1;
     std::vector<uint8_t> h_desc;       /* host image of d_desc: level tables + pack tiles */
     std::vector<LevelLaunch> launches_generic, launches_tile;
     size_t pack_off = 0; int npack = 0; int pack_maxw = 0, pack_maxh = 0;
@@ -174,6 +180,9 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     }
     c->probe_parser = j2k_parser_new();
     if (!c->probe_parser) { (void)hipFree(c->d_tables); delete c; return HTJ2K_ERR_ENOMEM; }
+    const char *hm = getenv("HTJ2K_HT");
+    if (hm && !strcmp(hm, "fused")) c->ht_mode = 0;
+    if (hm && !strcmp(hm, "split")) c->ht_mode = 1;
     const char *m = getenv("HTJ2K_IDWT");
     if (m && !strcmp(m, "generic")) c->idwt_mode = 0;
     if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
@@ -193,6 +202,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
 {
     if (!c || !name) return HTJ2K_ERR_EINVAL;
     if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
     return HTJ2K_ERR_EINVAL;
@@ -206,7 +216,8 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     if (!j) return;
     if (j->stream) (void)hipStreamSynchronize(j->stream);
     j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
-    j->d_t0.release(); j->d_t1.release(); j->d_desc.release();
+    j->d_t0.release(); j->d_t1.release(); j->d_desc.release(); j->d_qsym.release(); j->d_qoff.release();
+    j->d_msu.release(); j->d_vlcu.release(); j->d_melu.release();
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
@@ -348,7 +359,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 /* LDS windows of the HT kernel are sized from the largest cleanup prefix / suffix, quad row
  * and (for blocks with refinement passes) state bitmap in the table */
 static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const uint8_t *const *bases,
-                        const uint32_t *base_of_block, HtLds *out)
+                        const uint32_t *base_of_block, HtLds *out, HtLds *out_ext = nullptr)
 {
     uint32_t max_p = 0, max_s = 2, max_qw = 1, bm_words = 0;
     for (int i = 0; i < nblocks; i++) {
@@ -384,6 +395,18 @@ static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const
     L.bm_words = bm_words;
     L.off_bm = (uint32_t)off;  off += (size_t)4 * bm_words * 4;
     L.total = (uint32_t)align_up(off, 16);
+    if (out_ext) {                                       /* MagSgn-only kernel: bit array, exponents, bitmaps */
+        HtLds &X = *out_ext;
+        size_t o = 0;
+        X = L;
+        X.off_ms = 0; o += (size_t)X.ms_words * 4;
+        X.off_vlc = (uint32_t)o; X.vlc_words = 0;
+        X.off_suf = (uint32_t)o; X.suf_bytes = 0;
+        X.off_qinfo = (uint32_t)o; o += (size_t)2 * max_qw * 4;
+        X.off_E = (uint32_t)o; o += align_up((size_t)2 * (2 * max_qw + 8), 4);
+        X.off_bm = (uint32_t)o; o += (size_t)4 * bm_words * 4;
+        X.total = (uint32_t)align_up(o, 16);
+    }
     if ((int)L.total > 160 * 1024) {
         clog(c, LOG_ERROR, "a codeblock needs %u bytes of LDS\n", L.total);
         return HTJ2K_ERR_PATCHWELCOME;
@@ -509,7 +532,27 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             bases[f] = F.plan->bytes;
             for (int i = 0; i < F.plan->nblocks; i++) { bob[F.block_base + i] = f; rel[F.block_base + i] = F.plan->blocks[i]; }
         }
-        if ((r = build_ht_lds(c, rel.data(), (int)rel.size(), bases.data(), bob.data(), &j->lds)) < 0) return r;
+        if ((r = build_ht_lds(c, rel.data(), (int)rel.size(), bases.data(), bob.data(), &j->lds, &j->lds_ext)) < 0) return r;
+        j->max_qw = j->lds.max_qw;
+    }
+    {
+        /* blocks are independent: order the table by quad count so that the 64 lanes of a k_ht_vlc
+         * wave (one lane per block) run similar trip counts; then lay the quad-symbol arrays out */
+        std::stable_sort(j->blocks.begin(), j->blocks.end(), [](const J2kBlock &a, const J2kBlock &b) {
+            const int ka = a.npasses ? ((a.w + 1) >> 1) * ((a.h + 1) >> 1) : 0;
+            const int kb = b.npasses ? ((b.w + 1) >> 1) * ((b.h + 1) >> 1) : 0;
+            if (ka != kb) return ka > kb;
+            return a.w > b.w;
+        });
+        j->qoff.resize(j->blocks.size() + 1);
+        size_t q = 0;
+        for (size_t i = 0; i < j->blocks.size(); i++) {
+            j->qoff[i] = (uint32_t)q;
+            const J2kBlock &b = j->blocks[i];
+            if (b.npasses) q += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
+        }
+        if (q > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
+        j->nquads = q;
     }
     const size_t coef_bytes = (j->nsamples + 64) * sizeof(uint32_t);
     const int nblocks = (int)j->blocks.size();
@@ -519,6 +562,10 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t0.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
+    if ((r = j->d_qsym.ensure((j->nquads + 64) * sizeof(uint32_t))) < 0) return r;
+    if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
+    if ((r = j->d_msu.ensure(j->nbytes + 256)) < 0 || (r = j->d_vlcu.ensure(j->nbytes + 256)) < 0 ||
+        (r = j->d_melu.ensure(j->nbytes + 256)) < 0) return r;
     for (int f = 0; f < j->nframes; f++) {
         FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
@@ -541,8 +588,10 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_bytes.p + F.bytes_base, F.plan->bytes, F.plan->nbytes,
                                       hipMemcpyHostToDevice, j->stream));
     }
-    if (nblocks)
+    if (nblocks) {
         HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, j->blocks.data(), (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
+        HIP_TRY(c, hipMemcpyAsync(j->d_qoff.p, j->qoff.data(), j->qoff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+    }
     HIP_TRY(c, hipEventRecord(j->ev[1], j->stream));
     j->uploaded = 1;
     return 0;
@@ -621,11 +670,34 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
         if (nblocks) {
             HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
-            if ((int)j->lds.total > 48 * 1024)
-                HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
-            hipLaunchKernelGGL(k_ht_decode, dim3(nblocks), dim3(64), j->lds.total, j->stream,
-                               (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                               (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds);
+            const size_t vlc_lds = 4096 + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
+            if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
+                if (vlc_lds > 48 * 1024)
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
+                if ((int)j->lds_ext.total > 48 * 1024)
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
+                const uint32_t us_words = j->lds.ms_words > j->lds.vlc_words ? j->lds.ms_words : j->lds.vlc_words;
+                if (us_words * 4 > 48 * 1024)
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(us_words * 4)));
+                hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_words * 4, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                   (uint32_t *)j->d_msu.p, (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                   (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
+                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, getenv("HTJ2K_DBG") ? atoi(getenv("HTJ2K_DBG")) : 0);
+                hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                   (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
+                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, (const uint32_t *)j->d_msu.p);
+            } else {
+                if ((int)j->lds.total > 48 * 1024)
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
+                hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                   (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds,
+                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+            }
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
@@ -1000,31 +1072,67 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
 {
     if (!c || !blocks || nblocks <= 0 || !bytes || !coef) return HTJ2K_ERR_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    struct { HtLds lds; } tmp;
+    struct { HtLds lds, ext; } tmp;
     const uint8_t *bases[1] = { bytes };
-    int r = build_ht_lds(c, (const J2kBlock *)blocks, nblocks, bases, nullptr, &tmp.lds);
+    int r = build_ht_lds(c, (const J2kBlock *)blocks, nblocks, bases, nullptr, &tmp.lds, &tmp.ext);
     if (r < 0) return r;
-    DevBuf db, dby, dc, ds;
+    std::vector<uint32_t> qoff(nblocks + 1);
+    size_t nq = 0;
+    for (int i = 0; i < nblocks; i++) {
+        const J2kBlock &b = ((const J2kBlock *)blocks)[i];
+        qoff[i] = (uint32_t)nq;
+        if (b.npasses) nq += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
+    }
+    DevBuf db, dby, dc, ds, dq, dqo, du[3];
+    if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
+        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 || (r = du[2].ensure(nbytes + 256)) < 0) {
+        dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
+        return r;
+    }
     if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
         (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0) {
-        db.release(); dby.release(); dc.release(); ds.release();
+        db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
         return r;
     }
     hipError_t e = hipMemcpy(db.p, blocks, (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dby.p, bytes, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
-    if (e == hipSuccess && (int)tmp.lds.total > 48 * 1024)
-        e = hipFuncSetAttribute((const void *)k_ht_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.lds.total);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_ht_decode, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
-                           (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds);
-        e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(dqo.p, qoff.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice);
+    const size_t vlc_lds = 4096 + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
+    if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
+        if (vlc_lds > 48 * 1024)
+            e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
+        if (e == hipSuccess && (int)tmp.ext.total > 48 * 1024)
+            e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
+        if (e == hipSuccess) {
+            const uint32_t us_words = tmp.lds.ms_words > tmp.lds.vlc_words ? tmp.lds.ms_words : tmp.lds.vlc_words;
+            if (us_words * 4 > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(us_words * 4));
+            hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_words * 4, 0, (const J2kBlock *)db.p, nblocks,
+                               (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, (uint32_t *)du[2].p, us_words);
+            hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
+                               (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
+                               tmp.lds.max_qw, (const uint32_t *)du[1].p, (const uint32_t *)du[2].p, 0);
+            hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), tmp.ext.total, 0, (const J2kBlock *)db.p, nblocks,
+                               (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.ext,
+                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p);
+            e = hipDeviceSynchronize();
+        }
+    } else if (e == hipSuccess) {
+        if ((int)tmp.lds.total > 48 * 1024)
+            e = hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.lds.total);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
+                               (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+            e = hipDeviceSynchronize();
+        }
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
-    db.release(); dby.release(); dc.release(); ds.release();
+    db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
     if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_ht_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
     return 0;
 }
