@@ -54,7 +54,7 @@ struct htj2k_ctx {
     uint16_t *d_tables = nullptr;      /* 2 x 1024 CxtVLC decode entries */
     J2kParser *probe_parser = nullptr;
     htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
-    int idwt_mode = 1;                 /* 0 = generic two-pass kernels, 1 = fused LDS tile kernels */
+    int idwt_mode = 2;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = register/DPP tile kernel */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
 };
@@ -63,7 +63,7 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
     int type, level;
     int count;                         /* planes */
     size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_desc */
-    int max_lh, max_lv;
+    int max_lh, max_lv, min_l;         /* min_l: smallest line length of any plane (1-sample lines need k_idwt_tile) */
     double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv */
 };
 
@@ -186,6 +186,7 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     const char *m = getenv("HTJ2K_IDWT");
     if (m && !strcmp(m, "generic")) c->idwt_mode = 0;
     if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
+    if (m && !strcmp(m, "tile2")) c->idwt_mode = 2;
     *out = c;
     return 0;
 }
@@ -201,7 +202,7 @@ extern "C" void htj2k_set_log(htj2k_ctx *c, htj2k_log_fn fn, void *opaque)
 extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
 {
     if (!c || !name) return HTJ2K_ERR_EINVAL;
-    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
@@ -434,7 +435,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
     for (int lev = 0; lev < maxlev; lev++)
         for (int type = 0; type < 3; type++) {
             LevelLaunch g;
-            g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0;
+            g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0; g.min_l = 1 << 30;
             std::vector<DwtLevel> lv;
             std::vector<DwtTileArgs> ta;
             for (int t = 0; t < ntc; t++) {
@@ -454,6 +455,8 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                 ta.push_back(a);
                 if (d.lh > g.max_lh) g.max_lh = d.lh;
                 if (d.lv > g.max_lv) g.max_lv = d.lv;
+                if (d.lh < g.min_l) g.min_l = d.lh;
+                if (d.lv < g.min_l) g.min_l = d.lv;
                 g.alg_bytes += 8.0 * d.lh * d.lv;
             }
             if (lv.empty()) continue;
@@ -616,12 +619,24 @@ static void launch_generic_level(htj2k_job *j, const LevelLaunch &L)
 #define TILE_H 32
 
 template <int TYPE>
-static void launch_tile_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
+static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min_l, int count, int mode, hipStream_t s,
+                                const uint32_t *ll, const uint32_t *band, uint32_t *out)
 {
-    const DwtTileArgs *tab = (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off);
-    dim3 g((L.max_lh + TILE_W - 1) / TILE_W, (L.max_lv + TILE_H - 1) / TILE_H, L.count);
-    hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, j->stream, tab, ll,
-                       (const uint32_t *)j->d_coef.p, out);
+    if (mode >= 2 && min_l >= 2) {
+        constexpr int TW2 = 128 - 2 * Lift<TYPE>::HALO - 2, TH2 = 64;
+        dim3 g((max_lh + TW2 - 1) / TW2, (max_lv + TH2 - 1) / TH2, count);
+        hipLaunchKernelGGL((k_idwt_tile2<TYPE>), g, dim3(256), 0, s, (const DwtTileArgs *)tab, ll, band, out);
+    } else {
+        dim3 g((max_lh + TILE_W - 1) / TILE_W, (max_lv + TILE_H - 1) / TILE_H, count);
+        hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, s, (const DwtTileArgs *)tab, ll, band, out);
+    }
+}
+
+template <int TYPE>
+static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
+{
+    launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
+                              j->stream, ll, (const uint32_t *)j->d_coef.p, out);
 }
 
 static hipEvent_t lev_event(htj2k_job *j)
@@ -636,7 +651,6 @@ static hipEvent_t lev_event(htj2k_job *j)
 
 static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile)
 {
-    (void)c;
     j->lev_ev_used = 0;
     j->lev_bytes.clear();
     const std::vector<LevelLaunch> &LL = use_tile ? j->launches_tile : j->launches_generic;
@@ -650,9 +664,9 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile)
         } else {
             const uint32_t *ll = buf_ptr(j, L.level == 0 ? 0 : 1 + ((L.level - 1) & 1));
             uint32_t *out = buf_ptr(j, 1 + (L.level & 1));
-            if (L.type == J2K_DWT53) launch_tile_level<J2K_DWT53>(j, L, ll, out);
-            else if (L.type == J2K_DWT97) launch_tile_level<J2K_DWT97>(j, L, ll, out);
-            else launch_tile_level<J2K_DWT97_INT>(j, L, ll, out);
+            if (L.type == J2K_DWT53) launch_tile_level<J2K_DWT53>(c, j, L, ll, out);
+            else if (L.type == J2K_DWT97) launch_tile_level<J2K_DWT97>(c, j, L, ll, out);
+            else launch_tile_level<J2K_DWT97_INT>(c, j, L, ll, out);
         }
         hipEvent_t e1 = lev_event(j);
         if (e1) (void)hipEventRecord(e1, j->stream);
@@ -919,9 +933,8 @@ static void planeset_launch_level(const PlaneSet &P, int lev, int mode, int kth,
     } else {
         const uint32_t *ll = kth == 0 ? coef : ((kth - 1) & 1) ? t1 : t0;
         uint32_t *out = (kth & 1) ? t1 : t0;
-        dim3 g((P.lh[lev] + TILE_W - 1) / TILE_W, (P.lv[lev] + TILE_H - 1) / TILE_H, P.nplanes);
-        hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, s, (const DwtTileArgs *)d_tab, ll,
-                           (const uint32_t *)coef, out);
+        launch_tile_generic<TYPE>(d_tab, P.lh[lev], P.lv[lev], P.lh[lev] < P.lv[lev] ? P.lh[lev] : P.lv[lev], P.nplanes, mode, s,
+                                  ll, (const uint32_t *)coef, out);
     }
 }
 

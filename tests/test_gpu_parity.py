@@ -46,7 +46,7 @@ def test_kats_on_gpu(dec, kat):
     assert st.n_block_errors == 0
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["idwt_generic", "idwt_tile"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["idwt_generic", "idwt_tile", "idwt_tile2"])
 @pytest.mark.parametrize("name", sorted(streams.CASES))
 def test_frames_match_oracle(dec, orc, name, mode):
     data, kw = streams.get(name)
@@ -59,7 +59,7 @@ def test_frames_match_oracle(dec, orc, name, mode):
     finally:
         dec.set_int("bitexact", 0)
         dec.set_int("reduction_factor", 0)
-        dec.set_int("idwt_mode", 1)
+        dec.set_int("idwt_mode", 2)
     assert (info.width, info.height, info.pix_fmt, info.bits_per_raw_sample) == \
            (info_o.width, info_o.height, info_o.pix_fmt, info_o.bits_per_raw_sample)
     assert consumed == consumed_o
@@ -84,7 +84,7 @@ def test_stage_planes_match_oracle(dec, orc, name):
             assert a.dtype == b.dtype
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantised plane %d" % tc
         orc.idwt()
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             dec.set_int("idwt_mode", mode)
             job.run(1).run(2).wait()
             for tc in range(ntc):
@@ -95,7 +95,7 @@ def test_stage_planes_match_oracle(dec, orc, name):
         job.free()
     finally:
         dec.set_int("bitexact", 0)
-        dec.set_int("idwt_mode", 1)
+        dec.set_int("idwt_mode", 2)
 
 
 def test_idwt_random_borders(dec):
@@ -115,11 +115,11 @@ def test_idwt_random_borders(dec):
             else:
                 p = rng.integers(-3000, 3000, (h, w)).astype(np.int32) * (256 if typ == 2 else 1)
             want = oracle.idwt(p, border, lev, typ)
-            for mode in (0, 1):
+            for mode in (0, 1, 2):
                 dec.set_int("idwt_mode", mode)
                 got = dec.idwt(p, border, lev, typ)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (border, lev, typ, mode)
-    dec.set_int("idwt_mode", 1)
+    dec.set_int("idwt_mode", 2)
 
 
 def test_idwt_53_wraparound(dec):
@@ -128,10 +128,10 @@ def test_idwt_53_wraparound(dec):
     p = rng.integers(-2**31, 2**31 - 1, (70, 90), dtype=np.int64).astype(np.int32)
     border = [[1, 91], [0, 70]]
     want = oracle.idwt(p, border, 3, 1)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         dec.set_int("idwt_mode", mode)
         assert np.array_equal(dec.idwt(p, border, 3, 1), want)
-    dec.set_int("idwt_mode", 1)
+    dec.set_int("idwt_mode", 2)
 
 
 def test_mct_kernels(dec):
