@@ -40,15 +40,34 @@ struct HtLds {
 };
 
 #define HT_ERR_INVALID 1   /* the reference returns AVERROR_INVALIDDATA; block left zero */
+#define HT_MEL_SYMS  1344  /* MEL symbols a block can consume: <= 1024 quads + <= 256 first-row pairs, rounded up */
+#define HT_MEL_WORDS (HT_MEL_SYMS / 32 + 2)
+#define HT_UVLC_ENTRIES (5 * 64)
 
+/* inclusive prefix sum over the 64 lanes with DPP: Hillis-Steele inside each row of 16 lanes
+ * (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3
+ * (gfx9 DPP controls; lanes without a source keep `old` = 0) */
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
+/* same-wave LDS hand-off: the LDS executes a wave's instructions in order, only the compiler
+ * must not reorder across this point (a one-wave workgroup needs no s_barrier and, above all,
+ * no vmcnt(0) wait for the row stores that __syncthreads() would add) */
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 /* dequantise one sign-magnitude sample (bit 31 sign, magnitude LSB at 31 - M_b) */
@@ -257,7 +276,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                 atomicOr(&ms[off >> 5], byte << (off & 31));
                 if ((off & 31) > 24) atomicOr(&ms[(off >> 5) + 1], byte >> (32 - (off & 31)));
             }
-            base += __shfl(incl, 63, 64);
+            base += wave_last(incl);
         }
         ms_total = base;
     }
@@ -283,7 +302,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                 atomicOr(&vlcw[off >> 5], v << (off & 31));
                 if ((off & 31) > 24) atomicOr(&vlcw[(off >> 5) + 1], v >> (32 - (off & 31)));
             }
-            base += __shfl(incl, 63, 64);
+            base += wave_last(incl);
         }
     }
     for (uint32_t i = lane; !EXTERNAL_VLC && i < Scup; i += 64) {       /* MEL reads the (patched) suffix bytes */
@@ -320,7 +339,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
 
         /* ---- stage 1: serial quad-row decode on lane 0 ---- */
         if (EXTERNAL_VLC) {
-            for (int q = lane; q < qw; q += 64) qcur[q] = qglob[row * qw + q];
+            /* symbols are read straight from global in stage 2 */
         } else if (lane == 0) {
             const uint16_t *table = tbl + (row ? 1024 : 0);
             int rho_left = 0;
@@ -389,7 +408,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                     qcur[qx + k] = (uint32_t)rho[k] | ((uint32_t)ek[k] << 4) | ((uint32_t)e1[k] << 8) | ((uint32_t)u[k] << 16);
             }
         }
-        __syncthreads();
+        if (!EXTERNAL_VLC) __syncthreads();
 
         /* ---- stage 2: MagSgn of the quad row, lanes = sample columns ---- */
         const int ncols = 2 * qw;
@@ -398,7 +417,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             const int col = c0 + lane;
             const bool act = col < ncols;
             const int q = col >> 1;
-            const uint32_t qi = act ? qcur[q] : 0;
+            const uint32_t qi = act ? (EXTERNAL_VLC ? qglob[row * qw + q] : qcur[q]) : 0;
             const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
             int kappa = 1;
             if (row > 0 && act) {                      /* :855-885; Eprev[-1] and Eprev[ncols] are 0 */
@@ -442,7 +461,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                 }
             }
             if (act) Ecur[col] = (uint8_t)Ebot;
-            ms_pos += __shfl(incl, 63, 64);
+            ms_pos += wave_last(incl);
 
             /* raster positions of this lane's two samples; odd sizes: the outside half of the
              * border quads is discarded (:976-1007) */
@@ -463,7 +482,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             }
         }
         if (__any(row_err)) err = HT_ERR_INVALID;
-        __syncthreads();
+        if (EXTERNAL_VLC) wave_lds_fence(); else __syncthreads();
     }
 
     if (err) {
@@ -615,7 +634,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
             atomicOr(&sw[off >> 5], byte << (off & 31));
             if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], byte >> (32 - (off & 31)));
         }
-        base += __shfl(incl, 63, 64);
+        base += wave_last(incl);
     }
     __syncthreads();
     for (uint32_t i = lane; i < nms; i += 64) {
@@ -649,7 +668,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
             atomicOr(&sw[off >> 5], v << (off & 31));
             if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], v >> (32 - (off & 31)));
         }
-        base += __shfl(incl, 63, 64);
+        base += wave_last(incl);
     }
     __syncthreads();
     for (uint32_t i = lane; i < nsw; i += 64) vlO[i] = sw[i];
@@ -682,7 +701,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
                 atomicOr(&sw[(off >> 5) + 1], v << (32 - spill));
             }
         }
-        base += __shfl(incl, 63, 64);
+        base += wave_last(incl);
     }
     __syncthreads();
     for (uint32_t i = lane; i < nsw; i += 64) {            /* 0xFF bytes forever past the segment */
@@ -693,14 +712,6 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     }
 }
 
-/* ---- k_ht_vlc: one lane per codeblock ----
- * Bit positions instead of streaming buffers: the un-stuffed VLC and MEL streams are plain bit
- * arrays, so a lane only tracks `vpos` / `mpos`.  A quad pair consumes at most 38 VLC bits
- * (2 x 7 codeword + 2 x (3 + 5 + 4) U-VLC) and 18 MEL bits (3 symbols x (1 + 5)), hence the
- * four VLC dwords / three MEL dwords that start at the word holding the CURRENT position also
- * cover everything the NEXT pair can touch.  Each iteration therefore issues exactly one
- * dwordx4 and one dwordx3 load for the next iteration and waits for them only at its end:
- * no queues, no refill branches, no data-dependent control flow around memory. */
 struct Win128 { uint32_t w0, w1, w2, w3; uint32_t base; };   /* base = word index of w0 */
 
 __device__ __forceinline__ uint64_t vlc_window(const Win128 &W, uint32_t pos)
@@ -715,39 +726,20 @@ __device__ __forceinline__ uint64_t vlc_window(const Win128 &W, uint32_t pos)
     return sh ? ((lo >> sh) | ((uint64_t)c << (64 - sh))) : lo;
 }
 
-__device__ __forceinline__ uint32_t mel_window(const Win128 &W, uint32_t pos)
+/* U-VLC prefix table (T.814 7.3.6 / jpeg2000htdec.c:338-352, 666-712): index = mode * 64 + 6 stream
+ * bits; mode 0 no offset, 1 quad 0 only, 2 quad 1 only, 3 both, 4 both in the first quad row
+ * after a MEL 0 (if prefix 1 > 2 the second value is a single bit + 1).
+ * entry: p1 | p2 << 3 | prefix bits << 6 | suffix-1 bits << 9 | suffix-2 bits << 12 */
+__host__ __device__ inline uint16_t ht_uvlc_entry(int mode, uint32_t v)
 {
-    /* 32 stream bits starting at bit `pos`, first bit in the MSB (words are MSB-first) */
-    const uint32_t off = pos - (W.base << 5);
-    const uint32_t k = off >> 5, sh = off & 31;
-    const uint32_t a = k == 0 ? W.w0 : W.w1;
-    const uint32_t b = k == 0 ? W.w1 : W.w2;
-    return sh ? ((a << sh) | (b >> (32 - sh))) : a;
-}
-
-/* jpeg2000_decode_mel_sym (jpeg2000htdec.c:462-495) on a 32-bit MSB-first window; `en` = false
- * leaves everything untouched.  Returns the symbol; `m` is advanced past the consumed bits. */
-struct MelState { int k, run, one; };
-__device__ __forceinline__ int mel_sym(MelState &S, uint32_t &m, uint32_t &mused, bool en)
-{
-    const bool start = en && S.run == 0 && S.one == 0;
-    const int eval = (int)((0x5433222111000ull >> (4 * S.k)) & 0xF);
-    const uint32_t b = m >> 31;
-    const int r0 = eval ? (int)((m << 1) >> (32 - eval)) : 0;
-    const uint32_t used = start ? (b ? 1u : 1u + (uint32_t)eval) : 0u;
-    if (start) {
-        S.run = b ? (1 << eval) : r0;
-        S.k = b ? (S.k < 12 ? S.k + 1 : 12) : (S.k > 0 ? S.k - 1 : 0);
-        S.one = b ? 0 : 1;
-    }
-    m <<= used;
-    mused += used;
-    int ret = 0;
-    if (en) {
-        if (S.run > 0) S.run--;
-        else { S.one = 0; ret = 1; }
-    }
-    return ret;
+    const int pv[8] = { 5, 1, 2, 1, 3, 1, 2, 1 }, pl[8] = { 3, 1, 2, 1, 3, 1, 2, 1 };
+    int p1 = 0, p2 = 0, lp = 0;
+    if (mode == 1 || mode == 3 || mode == 4) { p1 = pv[v & 7]; lp = pl[v & 7]; }
+    if (mode == 4 && p1 > 2) { p2 = (int)((v >> lp) & 1) + 1; lp += 1; }
+    else if (mode >= 2) { const uint32_t w = v >> lp; p2 = pv[w & 7]; lp += pl[w & 7]; }
+    const int s1 = p1 < 3 ? 0 : (p1 == 3 ? 1 : 5);
+    const int s2 = (mode == 4 && p1 > 2) ? 0 : (p2 < 3 ? 0 : (p2 == 3 ? 1 : 5));
+    return (uint16_t)(p1 | (p2 << 3) | (lp << 6) | (s1 << 9) | (s2 << 12));
 }
 
 __global__ void __launch_bounds__(64)
@@ -758,14 +750,17 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint16_t *tbl = (uint16_t *)smem;
+    uint16_t *utbl = (uint16_t *)(smem + 4096);          /* HT_UVLC_ENTRIES entries */
     /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
      * dwords is odd so the 64 lanes hit distinct banks */
-    uint8_t *rho_rows = smem + 4096;
+    uint8_t *rho_rows = smem + 4096 + 1024;
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int lane = threadIdx.x;
     const int bi = blockIdx.x * 64 + lane;
     for (int i = lane; i < 1024; i += 64)
         ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+    for (int i = lane; i < HT_UVLC_ENTRIES; i += 64)
+        utbl[i] = ht_uvlc_entry(i >> 6, (uint32_t)(i & 63));
     __syncthreads();
 
     int qw = 0, qh = 0;
@@ -788,12 +783,14 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     }
     const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
     uint8_t *myrho = rho_rows + lane * pitch;
-    uint32_t vpos = 4, mpos = 0;                         /* the first 4 VLC bits are the Scup nibble (:283-295) */
-    MelState MS = { 0, 0, 0 };
-    Win128 VW = { 0, 0, 0, 0, 0 }, MW = { 0, 0, 0, 0, 0 };
+    uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
+    Win128 VW = { 0, 0, 0, 0, 0 };
+    /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
+     * adaptive run-length state machine only runs in a rarely taken refill path that decodes
+     * up to six codewords (>= 6, typically >= 32 symbols) from the un-stuffed MEL bits */
+    uint64_t msyms = 0; int mcnt = 0; uint32_t mbit = 0; int mel_k = 0;
     if (qh > 0) {
         VW.w0 = vsrc[0]; VW.w1 = vsrc[1]; VW.w2 = vsrc[2]; VW.w3 = vsrc[3];
-        MW.w0 = msrc[0]; MW.w1 = msrc[1]; MW.w2 = msrc[2];
     }
     int ctx_run = 0;
     for (int row = 0; row < qh; row++) {
@@ -805,15 +802,35 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         for (int qx = 0; qx < qw && !(dbg & 2); qx += 2) {
             const bool pair = qx + 1 < qw;
             /* loads for the NEXT iteration, based at the word of the current positions */
-            Win128 VN, MN;
-            VN.base = vpos >> 5; MN.base = mpos >> 5;
+            Win128 VN;
+            VN.base = vpos >> 5;
             {
-                const uint32_t *pv = vsrc + VN.base, *pm = msrc + MN.base;
+                const uint32_t *pv = vsrc + VN.base;
                 VN.w0 = pv[0]; VN.w1 = pv[1]; VN.w2 = pv[2]; VN.w3 = pv[3];
-                MN.w0 = pm[0]; MN.w1 = pm[1]; MN.w2 = pm[2]; MN.w3 = 0;
+            }
+            if (mcnt < 3) {                              /* a pair uses at most 3 MEL symbols */
+                const uint32_t *pm = msrc + (mbit >> 5);
+                const uint32_t sh = mbit & 31;
+                /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36 */
+                uint64_t mw = ((uint64_t)pm[0] << 32) | pm[1];
+                mw = sh ? ((mw << sh) | ((uint64_t)pm[2] >> (32 - sh))) : mw;
+#pragma unroll
+                for (int cw = 0; cw < 6; cw++) {
+                    const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
+                    const int b = (int)(mw >> 63);
+                    const int run = b ? (1 << eval) : (eval ? (int)((mw << 1) >> (64 - eval)) : 0);
+                    const int nsy = run + (b ? 0 : 1);
+                    if (mcnt + nsy <= 64) {              /* otherwise leave the codeword for the next refill */
+                        if (!b) msyms |= 1ull << ((mcnt + run) & 63);
+                        mcnt += nsy;
+                        const int used = b ? 1 : 1 + eval;
+                        mw <<= used; mbit += used;
+                        mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
+                    }
+                }
             }
             const uint64_t vwin = vlc_window(VW, vpos);
-            uint32_t m = mel_window(MW, mpos), mused = 0;
+            uint32_t m = (uint32_t)msyms, mused = 0;     /* next MEL symbols, LSB first */
             uint32_t a = (uint32_t)vwin, aused = 0;     /* the two codewords need <= 14 bits */
             int rho[2], uoff[2], ek[2], e1[2];
 #pragma unroll
@@ -825,7 +842,9 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 const int ctx = row0 ? ctx_run
                                      : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
                                         ((((ra >> 3) | (rar >> 1)) & 1) << 2));
-                const int msym = mel_sym(MS, m, mused, en && ctx == 0);
+                const bool mq = en && ctx == 0;
+                const int msym = (int)(m & 1);
+                m >>= mq ? 1 : 0; mused += mq ? 1 : 0;
                 const bool dec = en && (ctx != 0 || msym != 0);
                 const uint32_t e = dec ? table[(ctx << 7) | (a & 0x7F)] : 0u;
                 const uint32_t len = (e >> 1) & 7;
@@ -842,37 +861,34 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
              * fresh 32-bit window (<= 24 bits): decode order pfx1 pfx2 sfx1 sfx2 ext1 ext2; first
              * row with both offsets set: one MEL symbol, 1 => both u get +2, 0 and pfx1 > 2 => u2
              * is a single bit + 1 */
-            uint32_t u32w = (uint32_t)(vwin >> aused), uused = 0;
+            uint32_t u32w = (uint32_t)(vwin >> aused), uused;
             const bool both = uoff[0] && uoff[1];
-            const int mel2 = mel_sym(MS, m, mused, row0 && both);
-            const uint32_t b1 = u32w & 7;
-            const int p1 = uoff[0] ? (int)((0x12131215u >> (4 * b1)) & 0xF) : 0;
-            uint32_t d = uoff[0] ? ((0x12131213u >> (4 * b1)) & 0xF) : 0u;
-            u32w >>= d; uused += d;
-            const bool special = row0 && both && !mel2 && p1 > 2;
-            const uint32_t b2 = u32w & 7;
-            const int p2 = (uoff[1] && !special) ? (int)((0x12131215u >> (4 * b2)) & 0xF) : 0;
-            d = special ? 1u : (uoff[1] ? ((0x12131213u >> (4 * b2)) & 0xF) : 0u);
-            u32w >>= d; uused += d;
-            const int one_bit = (int)(b2 & 1);
-            d = p1 < 3 ? 0u : (p1 == 3 ? 1u : 5u);
+            const bool mq2 = row0 && both;
+            const int mel2 = (int)(m & 1);
+            mused += mq2 ? 1 : 0;
+            const int mode = (mq2 && !mel2) ? 4 : (uoff[0] | (uoff[1] << 1));
+            const uint32_t ue = utbl[(mode << 6) | (u32w & 63)];
+            const int p1 = ue & 7, p2 = (ue >> 3) & 7;
+            uint32_t d = (ue >> 6) & 7;
+            u32w >>= d; uused = d;
+            d = (ue >> 9) & 7;
             const int s1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
-            d = p2 < 3 ? 0u : (p2 == 3 ? 1u : 5u);
+            d = (ue >> 12) & 7;
             const int s2 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
             d = s1 >= 28 ? 4u : 0u;
             const int x1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
             d = s2 >= 28 ? 4u : 0u;
             const int x2 = (int)(u32w & ((1u << d) - 1)); uused += d;
-            const int bias = (row0 && both && mel2) ? 2 : 0;
+            const int bias = (mq2 && mel2) ? 2 : 0;
             const int u1 = uoff[0] ? bias + p1 + s1 + 4 * x1 : 0;
-            const int u2 = special ? one_bit + 1 : (uoff[1] ? bias + p2 + s2 + 4 * x2 : 0);
+            const int u2 = uoff[1] ? bias + p2 + s2 + 4 * x2 : 0;
             vpos += aused + uused;
-            mpos += mused;
+            msyms >>= mused; mcnt -= (int)mused;
             myrho[qx] = (uint8_t)rho[0];
             if (pair) myrho[qx + 1] = (uint8_t)rho[1];
             /* single wait point: next iteration's windows (loaded at the top) become current,
              * then this pair's symbols are stored -- they have a whole iteration to drain */
-            VW = VN; MW = MN;
+            VW = VN;
             if (!(dbg & 1)) {
                 rowout[qx] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
                 if (pair)

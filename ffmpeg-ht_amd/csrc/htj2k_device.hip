@@ -684,16 +684,17 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
         if (nblocks) {
             HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
-            const size_t vlc_lds = 4096 + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
+            const size_t vlc_lds = 4096 + 1024 + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = j->lds.ms_words > j->lds.vlc_words ? j->lds.ms_words : j->lds.vlc_words;
-                if (us_words * 4 > 48 * 1024)
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(us_words * 4)));
-                hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_words * 4, j->stream,
+                const uint32_t us_lds = us_words * 4;
+                if (us_lds > 48 * 1024)
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
+                hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_msu.p, (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
                 hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
@@ -1098,7 +1099,8 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
     }
     DevBuf db, dby, dc, ds, dq, dqo, du[3];
     if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
-        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 || (r = du[2].ensure(nbytes + 256)) < 0) {
+        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 ||
+        (r = du[2].ensure(nbytes + 256)) < 0) {
         dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
         return r;
     }
@@ -1112,7 +1114,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
     if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
     if (e == hipSuccess) e = hipMemcpy(dqo.p, qoff.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice);
-    const size_t vlc_lds = 4096 + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
+    const size_t vlc_lds = 4096 + 1024 + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
@@ -1120,9 +1122,10 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
             const uint32_t us_words = tmp.lds.ms_words > tmp.lds.vlc_words ? tmp.lds.ms_words : tmp.lds.vlc_words;
-            if (us_words * 4 > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(us_words * 4));
-            hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_words * 4, 0, (const J2kBlock *)db.p, nblocks,
+            const uint32_t us_lds = us_words * 4;
+            if (us_lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
+            hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, (uint32_t *)du[2].p, us_words);
             hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
