@@ -43,6 +43,8 @@ struct HtLds {
 #define HT_MEL_SYMS  1344  /* MEL symbols a block can consume: <= 1024 quads + <= 256 first-row pairs, rounded up */
 #define HT_MEL_WORDS (HT_MEL_SYMS / 32 + 2)
 #define HT_UVLC_ENTRIES (5 * 64)
+#define HT_VSTAGE_PITCH 28                  /* dwords per lane: 24 staged + pad; 7 x 16 B keeps b128 writes conflict-free */
+#define HT_VSTAGE_BYTES (64 * HT_VSTAGE_PITCH * 4)
 
 /* inclusive prefix sum over the 64 lanes with DPP: Hillis-Steele inside each row of 16 lanes
  * (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3
@@ -753,7 +755,11 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint16_t *utbl = (uint16_t *)(smem + 4096);          /* HT_UVLC_ENTRIES entries */
     /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
      * dwords is odd so the 64 lanes hit distinct banks */
-    uint8_t *rho_rows = smem + 4096 + 1024;
+    /* VLC words of every lane staged through LDS: 24 dwords (96 contiguous bytes) per lane are
+     * fetched once every 8 quad pairs and cover the 16 pairs after they are issued (16 x 38 bits
+     * + 31 < 768), so a lane touches 1-2 cache lines per refill instead of per pair */
+    uint32_t *vstage = (uint32_t *)(smem + 4096 + 1024);
+    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES;
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int lane = threadIdx.x;
     const int bi = blockIdx.x * 64 + lane;
@@ -784,13 +790,23 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
     uint8_t *myrho = rho_rows + lane * pitch;
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
-    Win128 VW = { 0, 0, 0, 0, 0 };
+    uint32_t *vst = vstage + lane * HT_VSTAGE_PITCH;
+    uint4 nx[6];                                         /* words in flight for the refill after next */
+    uint32_t sbase = 0, nbase = 0;                       /* word index of vst[0] / of nx[0] */
+    int it = 0;
     /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
      * up to six codewords (>= 6, typically >= 32 symbols) from the un-stuffed MEL bits */
     uint64_t msyms = 0; int mcnt = 0; uint32_t mbit = 0; int mel_k = 0;
+#pragma unroll
+    for (int jx = 0; jx < 6; jx++) nx[jx] = make_uint4(0u, 0u, 0u, 0u);
     if (qh > 0) {
-        VW.w0 = vsrc[0]; VW.w1 = vsrc[1]; VW.w2 = vsrc[2]; VW.w3 = vsrc[3];
+#pragma unroll
+        for (int jx = 0; jx < 6; jx++) {
+            uint4 q;
+            __builtin_memcpy(&q, vsrc + 4 * jx, 16);
+            *(uint4 *)(vst + 4 * jx) = q;
+        }
     }
     int ctx_run = 0;
     for (int row = 0; row < qh; row++) {
@@ -802,12 +818,17 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         for (int qx = 0; qx < qw && !(dbg & 2); qx += 2) {
             const bool pair = qx + 1 < qw;
             /* loads for the NEXT iteration, based at the word of the current positions */
-            Win128 VN;
-            VN.base = vpos >> 5;
-            {
-                const uint32_t *pv = vsrc + VN.base;
-                VN.w0 = pv[0]; VN.w1 = pv[1]; VN.w2 = pv[2]; VN.w3 = pv[3];
+            if ((it & 7) == 0) {
+                if (it) {                                /* words requested 8 pairs ago become the staged window */
+#pragma unroll
+                    for (int jx = 0; jx < 6; jx++) *(uint4 *)(vst + 4 * jx) = nx[jx];
+                    sbase = nbase;
+                }
+                nbase = vpos >> 5;
+#pragma unroll
+                for (int jx = 0; jx < 6; jx++) __builtin_memcpy(&nx[jx], vsrc + nbase + 4 * jx, 16);
             }
+            it++;
             if (mcnt < 3) {                              /* a pair uses at most 3 MEL symbols */
                 const uint32_t *pm = msrc + (mbit >> 5);
                 const uint32_t sh = mbit & 31;
@@ -829,7 +850,13 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                     }
                 }
             }
-            const uint64_t vwin = vlc_window(VW, vpos);
+            uint64_t vwin;
+            {
+                const uint32_t off = vpos - (sbase << 5), kw = off >> 5, sh = off & 31;
+                const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
+                const uint64_t lo = ((uint64_t)a1 << 32) | a0;
+                vwin = sh ? ((lo >> sh) | ((uint64_t)a2 << (64 - sh))) : lo;
+            }
             uint32_t m = (uint32_t)msyms, mused = 0;     /* next MEL symbols, LSB first */
             uint32_t a = (uint32_t)vwin, aused = 0;     /* the two codewords need <= 14 bits */
             int rho[2], uoff[2], ek[2], e1[2];
@@ -888,7 +915,6 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (pair) myrho[qx + 1] = (uint8_t)rho[1];
             /* single wait point: next iteration's windows (loaded at the top) become current,
              * then this pair's symbols are stored -- they have a whole iteration to drain */
-            VW = VN;
             if (!(dbg & 1)) {
                 rowout[qx] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
                 if (pair)

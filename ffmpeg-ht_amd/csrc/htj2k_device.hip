@@ -684,7 +684,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
         if (nblocks) {
             HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
-            const size_t vlc_lds = 4096 + 1024 + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
+            const size_t vlc_lds = 4096 + 1024 + HT_VSTAGE_BYTES + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
@@ -1114,7 +1114,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
     if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
     if (e == hipSuccess) e = hipMemcpy(dqo.p, qoff.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice);
-    const size_t vlc_lds = 4096 + 1024 + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
+    const size_t vlc_lds = 4096 + 1024 + HT_VSTAGE_BYTES + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
