@@ -183,6 +183,123 @@ __device__ __forceinline__ void ht_zero_window(uint32_t *dst, int w, int h, int 
 
 __device__ __forceinline__ int bm_get(const uint32_t *bm, int idx) { return (bm[idx >> 5] >> (idx & 31)) & 1; }
 
+/* ---- MagSgn fast path: blocks of at most 64 sample columns, no ROI shift ----
+ * lanes = sample columns; each lane owns the two samples of its column in the current quad row.
+ * Everything the row needs from its neighbours moves by DPP: the bottom-row exponents of the
+ * row above (kappa, jpeg2000htdec.c:855-885) through two wave shifts and a quad swap, the MagSgn
+ * bit offsets through the DPP prefix sum.  Both samples of a lane are cut out of one 96-bit LDS
+ * window.  The quad symbols of the next row are prefetched while the current one is processed. */
+__device__ __forceinline__ uint32_t ht_dpp_swap_pair(uint32_t v)   /* lane <-> lane ^ 1 */
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);          /* quad_perm [1,0,3,2] */
+}
+__device__ __forceinline__ uint32_t ht_dpp_left(uint32_t v)        /* lane i <- lane i-1, lane 0 <- 0 */
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t ht_dpp_right(uint32_t v)       /* lane i <- lane i+1, lane 63 <- 0 */
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+template <int TRANSFORM, bool REFINE>
+__device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
+                                                     uint32_t *__restrict__ dst, uint32_t *bm, int lane, int w, int h,
+                                                     int stride, int pLSB, int maxbp, int M_b, float fscale, int i_step,
+                                                     uint32_t last_wi)
+{
+    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1, ncols = 2 * qw;
+    const int col = lane;
+    const bool act = col < ncols;
+    const int q = col >> 1, sh = (col & 1) * 2;
+    const int bmW = w + 2;
+    const int dshift = 31 - M_b;
+    uint32_t ms_pos = 0, Eb = 0;
+    int err = 0;
+    uint32_t qi_next = act ? qglob[q] : 0u;
+    for (int row = 0; row < qh; row++) {
+        const uint32_t qi = qi_next;
+        if (row + 1 < qh) qi_next = act ? qglob[(row + 1) * qw + q] : 0u;
+        const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+        int kappa = 1;
+        if (row > 0) {
+            /* quad q spans columns 2q, 2q+1; it looks at the bottom exponents of columns 2q-1 .. 2q+2 */
+            /* own-lane neighbours cover columns c-1, c+1; together with the pair partner's
+             * (c^1)-1, (c^1)+1 that is exactly 2q-1 .. 2q+2 -- no lane-dependent select, so no
+             * DPP ends up under a divergent EXEC mask */
+            const uint32_t nbm = max(ht_dpp_left(Eb), ht_dpp_right(Eb));
+            const uint32_t pm = max(Eb, ht_dpp_swap_pair(Eb));
+            const int me = (int)max(pm, max(nbm, ht_dpp_swap_pair(nbm)));
+            const int gamma = (rho & (rho - 1)) != 0;
+            kappa = max(1, gamma * (me - 1));
+        }
+        const int U = kappa + uq;
+        if (act && U > maxbp) err = 1;
+        const int s_t = (rho >> sh) & 1, s_b = (rho >> (sh + 1)) & 1;
+        const int m_t = act ? s_t * U - ((ekq >> sh) & 1) : 0;
+        const int m_b = act ? s_b * U - ((ekq >> (sh + 1)) & 1) : 0;
+        const uint32_t nt = (uint32_t)max(m_t, 0), nb = (uint32_t)max(m_b, 0);
+        const uint32_t incl = wave_incl_scan_u32(nt + nb, lane);
+        const uint32_t pos = ms_pos + incl - nt - nb;
+        ms_pos += wave_last(incl);
+        /* 96-bit window: both samples (<= 62 bits) start at bit pos & 31 */
+        /* words last_wi .. last_wi + 2 are the all-ones continuation of the stream (:207-221) */
+        const uint32_t wi = min(pos >> 5, last_wi), bs = pos & 31;
+        const uint32_t w0 = ms[wi], w1 = ms[wi + 1], w2 = ms[wi + 2];
+        const uint64_t lo64 = ((uint64_t)w1 << 32) | w0;
+        const uint64_t win = bs ? ((lo64 >> bs) | ((uint64_t)w2 << (64 - bs))) : lo64;
+        uint32_t vt = (uint32_t)(win & ((1ull << nt) - 1));
+        uint32_t vb = (uint32_t)((win >> nt) & ((1ull << nb) - 1));
+        if (m_t > 0) vt += (uint32_t)((e1q >> sh) & 1) << m_t;
+        if (m_b > 0) vb += (uint32_t)((e1q >> (sh + 1)) & 1) << m_b;
+        uint32_t mu_t = 0, mu_b = 0;
+        Eb = 0;
+        if (m_t != 0) mu_t = ((((vt >> 1) + 1) << pLSB) | (1u << ((pLSB - 1) & 31))) | ((vt & 1) << 31);
+        if (m_b != 0) {
+            mu_b = ((((vb >> 1) + 1) << pLSB) | (1u << ((pLSB - 1) & 31))) | ((vb & 1) << 31);
+            Eb = (uint32_t)(32 - __clz((int)(vb | 1)));
+        }
+        if (!act) Eb = 0;
+        const int y0 = 2 * row;
+        if (act && col < w) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int y = y0 + r;
+                if (y >= h) continue;
+                const uint32_t smag = r ? mu_b : mu_t;
+                if (REFINE) {
+                    dst[(size_t)y * stride + col] = smag;
+                    if ((rho >> (sh + r)) & 1)
+                        atomicOr(&bm[((y + 1) * bmW + col + 1) >> 5], 1u << (((y + 1) * bmW + col + 1) & 31));
+                } else {
+                    const uint32_t mag = smag & 0x7FFFFFFFu;
+                    const bool neg = (smag >> 31) != 0;
+                    uint32_t outv;
+                    if (TRANSFORM == J2K_DWT53) {
+                        int v = (int)(mag >> dshift);
+                        if (neg) v = -v;
+                        if (i_step != 32768) {
+                            long long t = (long long)v * i_step;
+                            v = (int)(t < 0 ? -((-t) >> 16) : (t >> 16));
+                        }
+                        outv = (uint32_t)v;
+                    } else if (TRANSFORM == J2K_DWT97) {
+                        const int v = neg ? -(int)mag : (int)mag;
+                        outv = __float_as_uint((float)v * fscale);
+                    } else {
+                        int v = neg ? -(int)mag : (int)mag;
+                        v = (v + 32) >> 6;
+                        const long long t = (long long)v * i_step;
+                        outv = (uint32_t)(int)((t + (1 << 15)) >> 16);
+                    }
+                    dst[(size_t)y * stride + col] = outv;
+                }
+            }
+        }
+    }
+    return __any(err) ? HT_ERR_INVALID : 0;
+}
+
 /* EXTERNAL_VLC = false: the whole block in this kernel (stage 1 on lane 0).
  * EXTERNAL_VLC = true : stage 1 was done by k_ht_vlc (one LANE per codeblock, 64 serial decodes
  *                       per wavefront); the packed quad symbols come from `qsym` (qoff[b] is the
@@ -227,7 +344,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     }
     if (!err && maxbp >= 32) err = HT_ERR_INVALID;     /* :617 */
     /* LDS capacity is sized by the host from the same fields; never index past it */
-    if (!err && ((Pcup * 8 + 31) / 32 + 2 > L.ms_words || (uint32_t)qw > L.max_qw ||
+    if (!err && ((Pcup * 8 + 31) / 32 + 3 > L.ms_words || (uint32_t)qw > L.max_qw ||
                  (!EXTERNAL_VLC && ((Scup * 8 + 31) / 32 + 2 > L.vlc_words || Scup > L.suf_bytes))))
         err = HT_ERR_INVALID;
     if (err) {
@@ -264,6 +381,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         /* un-stuffed (and ones-padded) by k_ht_unstuff: a plain coalesced copy */
         const uint32_t *src = ms_u + (b.data_off >> 2);
         for (uint32_t i = lane; i < nms; i += 64) ms[i] = src[i];
+        if (lane == 0) ms[nms] = 0xFFFFFFFFu;
     } else {   /* MagSgn: forward, a byte after 0xFF advances 7 bits but ORs all 8 (jpeg2000htdec.c:207-221) */
         uint32_t base = 0;
         for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
@@ -335,7 +453,19 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     int ctx_run = 0;                                   /* first-row context carried along the row */
     const int bmW = w + 2;                             /* bitmap row pitch (1-cell border) */
 
-    for (int row = 0; row < qh && !err; row++) {
+    const bool fast = EXTERNAL_VLC && 2 * qw <= 64 && roi_shift == 0;
+    if (fast) {
+        if (z_blk > 1) {
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+        } else {
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+        }
+    }
+    for (int row = 0; row < qh && !err && !fast; row++) {
         uint32_t *qcur = qinfo + (row & 1) * L.max_qw, *qprev = qinfo + ((row & 1) ^ 1) * L.max_qw;
         uint8_t *Ecur = Earr + (row & 1) * Estride + 4, *Eprev = Earr + ((row & 1) ^ 1) * Estride + 4;
 

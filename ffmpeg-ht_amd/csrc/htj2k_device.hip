@@ -384,7 +384,7 @@ static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const
     }
     HtLds &L = *out;
     size_t off = 4096;                                   /* the two CxtVLC tables */
-    L.ms_words = (max_p * 8 + 31) / 32 + 2;
+    L.ms_words = (max_p * 8 + 31) / 32 + 3;
     L.off_ms = (uint32_t)off;  off += (size_t)L.ms_words * 4;
     L.vlc_words = (max_s * 8 + 31) / 32 + 2;
     L.off_vlc = (uint32_t)off; off += (size_t)L.vlc_words * 4;
