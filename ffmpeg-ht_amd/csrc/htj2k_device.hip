@@ -22,6 +22,7 @@
 #include "ht_kernels.hpp"
 #include "dwt_kernels.hpp"
 #include "pack_kernels.hpp"
+#include "dwt_stream.hpp"
 
 using namespace htj2k;
 
@@ -54,7 +55,9 @@ struct htj2k_ctx {
     uint16_t *d_tables = nullptr;      /* 2 x 1024 CxtVLC decode entries */
     J2kParser *probe_parser = nullptr;
     htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
-    int idwt_mode = 2;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = register/DPP tile kernel */
+    int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = LDS + register/DPP tile kernel,
+                                        * 3 = register-streaming kernel (dwt_stream.hpp) */
+    int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
 };
@@ -64,7 +67,9 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
     int count;                         /* planes */
     size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_desc */
     int max_lh, max_lv, min_l;         /* min_l: smallest line length of any plane (1-sample lines need k_idwt_tile) */
-    double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv */
+    double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv; fused final level:
+                                        * 4 * lh * lv read + the frame bytes written */
+    int nc = 0;                        /* 0: table of DwtTileArgs; 1/3/4: table of DwtFusedArgs (fused final level) */
 };
 
 struct FrameSlot {                     /* one frame of a batch */
@@ -97,6 +102,11 @@ struct htj2k_job {
     uint32_t max_qw = 1;
     std::vector<uint8_t> h_desc;       /* host image of d_desc: level tables + pack tiles */
     std::vector<LevelLaunch> launches_generic, launches_tile;
+    std::vector<LevelLaunch> launches_fused;   /* idwt_mode 3 with the pack stage fused into the final level */
+    std::vector<uint8_t> tile_fusable;         /* per PackTile */
+    std::vector<uint8_t> plane_fused;          /* per tilecomp: the last IDWT run never wrote its final plane */
+    bool any_fusable = false;
+    bool fused_last = false;                   /* the last run used launches_fused */
     size_t pack_off = 0; int npack = 0; int pack_maxw = 0, pack_maxh = 0;
     HtLds lds;
     int uploaded = 0, ran = 0;
@@ -187,6 +197,9 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     if (m && !strcmp(m, "generic")) c->idwt_mode = 0;
     if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
     if (m && !strcmp(m, "tile2")) c->idwt_mode = 2;
+    if (m && !strcmp(m, "stream")) c->idwt_mode = 3;
+    const char *fz = getenv("HTJ2K_FUSE");
+    if (fz) c->fuse_pack = atoi(fz) != 0;
     *out = c;
     return 0;
 }
@@ -202,7 +215,8 @@ extern "C" void htj2k_set_log(htj2k_ctx *c, htj2k_log_fn fn, void *opaque)
 extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
 {
     if (!c || !name) return HTJ2K_ERR_EINVAL;
-    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
+    if (!strcmp(name, "fuse_pack")) { c->fuse_pack = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
@@ -517,6 +531,123 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
             j->npack++;
         }
     }
+    /* ---- fused plan (idwt_mode 3): the final level of every fusable tile goes through
+     * k_idwt_stream_pack, which writes the frame; everything else as in launches_tile ---- */
+    j->launches_fused.clear();
+    j->tile_fusable.assign(j->npack, 0);
+    j->plane_fused.assign(ntc, 0);
+    j->any_fusable = false;
+    struct Group { int tc0, nc, comp0, pack_tile; };
+    std::vector<Group> groups;
+    std::vector<uint8_t> in_group(ntc, 0);
+    if (j->tile_ok) {
+        int ti = 0;
+        for (int f = 0; f < j->nframes; f++) {
+            const FrameSlot &F = j->frames[f];
+            const J2kPlan *pl = F.plan;
+            const int nc = pl->info.ncomponents;
+            for (int k = 0; k < pl->ntiles; k++, ti++) {
+                const int base = F.tc_base + k * nc;
+                auto final_ok = [&](const J2kTileComp &tc) {
+                    if (!tc.coded || tc.ndeclevels < 1) return false;
+                    const int lev = tc.ndeclevels - 1;
+                    return tc.linelen[lev][0] >= 2 && tc.linelen[lev][1] >= 2 && tc.linelen[lev][0] == tc.w && tc.linelen[lev][1] == tc.h;
+                };
+                auto same = [&](const J2kTileComp &a, const J2kTileComp &b) {
+                    const int lev = a.ndeclevels - 1;
+                    return a.w == b.w && a.h == b.h && a.ndeclevels == b.ndeclevels && a.transform == b.transform &&
+                           a.mod[lev][0] == b.mod[lev][0] && a.mod[lev][1] == b.mod[lev][1];
+                };
+                bool ok = nc >= 1 && nc <= 4;
+                for (int cc = 0; cc < nc && ok; cc++) ok = final_ok(j->tilecomps[base + cc]);
+                if (!ok) continue;
+                const J2kTileComp &t0 = j->tilecomps[base];
+                std::vector<Group> mine;
+                if (t0.pix_step > 1) {
+                    ok = nc == 3 || nc == 4;
+                    for (int cc = 1; cc < nc && ok; cc++)
+                        ok = same(t0, j->tilecomps[base + cc]) && j->tilecomps[base + cc].pix_step == t0.pix_step &&
+                             j->tilecomps[base + cc].out_plane == t0.out_plane;
+                    mine.push_back({ base, nc, 0, ti });
+                } else {
+                    int first = 0;
+                    if (t0.mct) {
+                        ok = nc >= 3 && same(t0, j->tilecomps[base + 1]) && same(t0, j->tilecomps[base + 2]);
+                        mine.push_back({ base, 3, 0, ti });
+                        first = 3;
+                    }
+                    for (int cc = first; cc < nc; cc++) mine.push_back({ base + cc, 1, cc, ti });
+                }
+                if (!ok) continue;
+                j->tile_fusable[ti] = 1;
+                j->any_fusable = true;
+                for (const Group &g : mine) {
+                    groups.push_back(g);
+                    for (int cc = 0; cc < g.nc; cc++) in_group[g.tc0 + cc] = 1;
+                }
+            }
+        }
+    }
+    if (j->any_fusable) {
+        auto level_args = [&](const J2kTileComp &tc, int lev) {
+            DwtTileArgs a;
+            a.g.plane_off = tc.plane_off; a.g.stride = tc.w;
+            a.g.lh = tc.linelen[lev][0]; a.g.lv = tc.linelen[lev][1];
+            a.g.mh = tc.mod[lev][0]; a.g.mv = tc.mod[lev][1];
+            a.g.last = (tc.transform == J2K_DWT97_INT && lev == tc.ndeclevels - 1) ? 1 : 0;
+            a.ll_off = tc.plane_off; a.ll_stride = tc.w;
+            a.out_off = tc.plane_off; a.out_stride = tc.w;
+            return a;
+        };
+        for (int lev = 0; lev < maxlev; lev++)
+            for (int type = 0; type < 3; type++) {
+                LevelLaunch g;
+                g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0; g.min_l = 1 << 30; g.nc = 0;
+                std::vector<DwtTileArgs> ta;
+                for (int t = 0; t < ntc; t++) {
+                    const J2kTileComp &tc = j->tilecomps[t];
+                    if (!tc.coded || tc.transform != type || lev >= tc.ndeclevels) continue;
+                    if (in_group[t] && lev == tc.ndeclevels - 1) continue;
+                    const DwtTileArgs a = level_args(tc, lev);
+                    ta.push_back(a);
+                    g.max_lh = std::max(g.max_lh, a.g.lh); g.max_lv = std::max(g.max_lv, a.g.lv);
+                    g.min_l = std::min(g.min_l, std::min(a.g.lh, a.g.lv));
+                    g.alg_bytes += 8.0 * a.g.lh * a.g.lv;
+                }
+                if (!ta.empty()) {
+                    g.count = (int)ta.size();
+                    while (j->h_desc.size() % 16) j->h_desc.push_back(0);
+                    g.table_off = j->h_desc.size();
+                    push_bytes(j->h_desc, ta.data(), ta.size() * sizeof(DwtTileArgs));
+                    j->launches_fused.push_back(g);
+                }
+                for (int nc = 1; nc <= 4; nc++) {
+                    LevelLaunch fz = g;
+                    fz.count = 0; fz.max_lh = fz.max_lv = 0; fz.alg_bytes = 0; fz.min_l = 1 << 30; fz.nc = nc;
+                    std::vector<DwtFusedArgs> fa;
+                    for (const Group &gr : groups) {
+                        const J2kTileComp &tc = j->tilecomps[gr.tc0];
+                        if (gr.nc != nc || tc.transform != type || tc.ndeclevels - 1 != lev) continue;
+                        DwtFusedArgs A;
+                        memset(&A, 0, sizeof(A));
+                        for (int cc = 0; cc < nc; cc++) A.a[cc] = level_args(j->tilecomps[gr.tc0 + cc], lev);
+                        A.ncomp = nc; A.pack_tile = gr.pack_tile; A.comp0 = gr.comp0;
+                        fa.push_back(A);
+                        fz.max_lh = std::max(fz.max_lh, A.a[0].g.lh); fz.max_lv = std::max(fz.max_lv, A.a[0].g.lv);
+                        fz.min_l = std::min(fz.min_l, std::min(A.a[0].g.lh, A.a[0].g.lv));
+                        const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + gr.pack_tile;
+                        fz.alg_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * (4.0 + PT->out_bytes);
+                    }
+                    if (fa.empty()) continue;
+                    fz.count = (int)fa.size();
+                    while (j->h_desc.size() % 16) j->h_desc.push_back(0);
+                    fz.table_off = j->h_desc.size();
+                    push_bytes(j->h_desc, fa.data(), fa.size() * sizeof(DwtFusedArgs));
+                    j->launches_fused.push_back(fz);
+                }
+            }
+        for (int t = 0; t < ntc; t++) j->plane_fused[t] = in_group[t];
+    }
     (void)c;
     return 0;
 }
@@ -618,11 +749,27 @@ static void launch_generic_level(htj2k_job *j, const LevelLaunch &L)
 #define TILE_W 64
 #define TILE_H 32
 
+/* rows per wave of the streaming kernels: enough strips to put several waves on every SIMD
+ * (1024 SIMDs), long enough that the HALO rows re-read per strip stay a few percent */
+static int stream_strip_rows(int max_lh, int max_lv, int count)
+{
+    const long cols = (max_lh + STREAM_TW - 1) / STREAM_TW;
+    const char *e = getenv("HTJ2K_STRIP");
+    if (e && atoi(e) >= 8) return atoi(e) & ~1;
+    int th = 128;
+    while (th > 16 && cols * ((max_lv + th - 1) / th) * count < 6144) th >>= 1;
+    return th;
+}
+
 template <int TYPE>
 static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min_l, int count, int mode, hipStream_t s,
                                 const uint32_t *ll, const uint32_t *band, uint32_t *out)
 {
-    if (mode >= 2 && min_l >= 2) {
+    if (mode >= 3 && min_l >= 2) {
+        const int th = stream_strip_rows(max_lh, max_lv, count);
+        dim3 g((max_lh + STREAM_TW - 1) / STREAM_TW, (max_lv + th - 1) / th, count);
+        hipLaunchKernelGGL((k_idwt_stream<TYPE>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th);
+    } else if (mode >= 2 && min_l >= 2) {
         constexpr int TW2 = 128 - 2 * Lift<TYPE>::HALO - 2, TH2 = 64;
         dim3 g((max_lh + TW2 - 1) / TW2, (max_lv + TH2 - 1) / TH2, count);
         hipLaunchKernelGGL((k_idwt_tile2<TYPE>), g, dim3(256), 0, s, (const DwtTileArgs *)tab, ll, band, out);
@@ -639,6 +786,19 @@ static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, 
                               j->stream, ll, (const uint32_t *)j->d_coef.p, out);
 }
 
+template <int TYPE>
+static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll)
+{
+    const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
+    dim3 g((L.max_lh + STREAM_TW - 1) / STREAM_TW, (L.max_lv + th - 1) / th, L.count);
+    const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
+    const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
+    const uint32_t *band = (const uint32_t *)j->d_coef.p;
+    if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
+    else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
+    else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
+}
+
 static hipEvent_t lev_event(htj2k_job *j)
 {
     if (j->lev_ev_used >= (int)j->lev_ev.size()) {
@@ -649,15 +809,20 @@ static hipEvent_t lev_event(htj2k_job *j)
     return j->lev_ev[j->lev_ev_used++];
 }
 
-static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile)
+static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
 {
     j->lev_ev_used = 0;
     j->lev_bytes.clear();
-    const std::vector<LevelLaunch> &LL = use_tile ? j->launches_tile : j->launches_generic;
+    const std::vector<LevelLaunch> &LL = fuse ? j->launches_fused : use_tile ? j->launches_tile : j->launches_generic;
     for (const LevelLaunch &L : LL) {
         hipEvent_t e0 = lev_event(j);
         if (e0) (void)hipEventRecord(e0, j->stream);
-        if (!use_tile) {
+        if (L.nc) {
+            const uint32_t *ll = buf_ptr(j, L.level == 0 ? 0 : 1 + ((L.level - 1) & 1));
+            if (L.type == J2K_DWT53) launch_fused_level<J2K_DWT53>(j, L, ll);
+            else if (L.type == J2K_DWT97) launch_fused_level<J2K_DWT97>(j, L, ll);
+            else launch_fused_level<J2K_DWT97_INT>(j, L, ll);
+        } else if (!use_tile) {
             if (L.type == J2K_DWT53) launch_generic_level<J2K_DWT53>(j, L);
             else if (L.type == J2K_DWT97) launch_generic_level<J2K_DWT97>(j, L);
             else launch_generic_level<J2K_DWT97_INT>(j, L);
@@ -719,31 +884,37 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
     }
     if (mask & 6) {
         const bool use_tile = c->idwt_mode != 0 && j->tile_ok;
+        const bool fuse = use_tile && c->idwt_mode == 3 && c->fuse_pack && (mask & 6) == 6 && j->any_fusable;
         if (mask & 2)
             for (int t = 0; t < ntc; t++) j->final_eff[t] = use_tile ? j->final_buf[t] : 0;
+        j->fused_last = fuse;
         /* one upload of all descriptor tables, pack source pointers patched for where the
          * planes are (or will be) after the IDWT */
         PackTile *T = (PackTile *)(j->h_desc.data() + j->pack_off);
         int ti = 0;
         for (int f = 0; f < j->nframes; f++) {
             const FrameSlot &F = j->frames[f];
-            for (int k = 0; k < F.plan->ntiles; k++, ti++)
+            for (int k = 0; k < F.plan->ntiles; k++, ti++) {
+                T[ti].fused = fuse && j->tile_fusable[ti];
                 for (int cc = 0; cc < T[ti].ncomp; cc++) {
                     const int t = F.tc_base + k * T[ti].ncomp + cc;
                     T[ti].c[cc].src = buf_ptr(j, j->final_eff[t]) + j->tilecomps[t].plane_off;
                 }
+            }
         }
         if (!(mask & 1)) HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
         HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
         if (mask & 2) {
-            int r = run_idwt(c, j, use_tile);
+            int r = run_idwt(c, j, use_tile, fuse);
             if (r < 0) return r;
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(j->ev[4], j->stream));
     }
     if (mask & 4) {
-        if (j->npack && j->pack_maxw > 0 && j->pack_maxh > 0) {
+        bool all_fused = j->fused_last;
+        for (size_t i = 0; all_fused && i < j->tile_fusable.size(); i++) all_fused = j->tile_fusable[i] != 0;
+        if (j->npack && j->pack_maxw > 0 && j->pack_maxh > 0 && !all_fused) {
             dim3 g((j->pack_maxw + 1023) / 1024, j->pack_maxh, j->npack);
             hipLaunchKernelGGL(k_mct_pack, g, dim3(256), 0, j->stream,
                                (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off));
@@ -814,6 +985,7 @@ extern "C" int htj2k_job_read_plane(htj2k_ctx *c, htj2k_job *j, int tc, void *ds
     const size_t n = (size_t)t.w * t.h * 4;
     if (dst_bytes < n) return HTJ2K_ERR_EINVAL;
     const int fb = j->final_eff.empty() ? 0 : j->final_eff[tc];
+    if (j->fused_last && !j->plane_fused.empty() && j->plane_fused[tc]) return HTJ2K_ERR_EINVAL;   /* never materialised */
     HIP_TRY(c, hipStreamSynchronize(j->stream));
     HIP_TRY(c, hipMemcpy(dst, buf_ptr(j, fb) + t.plane_off, n, hipMemcpyDeviceToHost));
     return 0;

@@ -38,11 +38,12 @@ struct PackTile {
     int32_t out_bytes;       /* 1: write_frame_8, 2: write_frame_16 */
     int32_t precision;       /* write_frame's `precision` argument */
     int32_t maxw, maxh;      /* largest component extent: the launch grid */
+    int32_t fused;           /* this run's final IDWT level writes the frame itself: k_mct_pack skips the tile */
 };
 
-/* One thread = 4 horizontally adjacent sample positions of every component of a tile:
- * 16-byte plane loads, the inverse MCT in registers, and the packed / planar output row
- * assembled into whole dwords (rgb24: 12 bytes per thread) instead of byte stores. */
+/* The per-position arithmetic and the stores are shared by k_mct_pack (planes in HBM) and by
+ * the fused final IDWT level (dwt_stream.hpp: samples still in registers).  A caller holds 4
+ * horizontally adjacent sample positions of up to 4 components in v[component][position]. */
 __device__ __forceinline__ int pack_value(const PackTile &T, const PackComp &C, int val)
 {
     val += 1 << (C.cbps - 1);
@@ -50,11 +51,123 @@ __device__ __forceinline__ int pack_value(const PackTile &T, const PackComp &C, 
     return val << (T.precision - C.cbps);
 }
 
+/* inverse MCT of components 0..2 (raw plane bits in, integers out) */
+__device__ __forceinline__ void pack_mct(int tr, int (&v)[4][4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s0 = (uint32_t)v[0][i], s1 = (uint32_t)v[1][i], s2 = (uint32_t)v[2][i];
+        if (tr == J2K_DWT53) {                          /* rct_int, jpeg2000dsp.c:78-91 */
+            const uint32_t i1 = s0 - (uint32_t)((int32_t)(s2 + s1) >> 2);
+            v[0][i] = (int32_t)(i1 + s2); v[1][i] = (int32_t)i1; v[2][i] = (int32_t)(i1 + s1);
+        } else if (tr == J2K_DWT97) {                   /* ict_float, :43-59, then lrintf (jpeg2000dec.c:2340) */
+            const float f0 = __uint_as_float(s0), f1 = __uint_as_float(s1), f2 = __uint_as_float(s2);
+            const float i0f = f0 + (1.402f * f2);
+            const float i1f = f0 - (0.34413f * f1) - (0.71414f * f2);
+            const float i2f = f0 + (1.772f * f1);
+            v[0][i] = __float2int_rn(i0f); v[1][i] = __float2int_rn(i1f); v[2][i] = __float2int_rn(i2f);
+        } else {                                        /* ict_int, :61-76 */
+            const int32_t a0 = (int32_t)s0, a1 = (int32_t)s1, a2 = (int32_t)s2;
+            v[0][i] = a0 + a2 + ((int)((26345U * (uint32_t)a2) + (1 << 15)) >> 16);
+            v[1][i] = a0 - ((int)((22553U * (uint32_t)a1) + (1 << 15)) >> 16)
+                         - ((int)((46802U * (uint32_t)a2) + (1 << 15)) >> 16);
+            v[2][i] = a0 + (2 * a1) + ((int)((-14942U * (uint32_t)a1) + (1 << 15)) >> 16);
+        }
+    }
+}
+
+/* component c: lrintf of a float plane that did not go through the MCT, DC shift, clip, << */
+__device__ __forceinline__ void pack_convert(const PackTile &T, int c, int (&v)[4])
+{
+    const PackComp &C = T.c[c];
+    const bool fl = C.transform == J2K_DWT97 && !(T.mct && c < 3);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int raw = fl ? __float2int_rn(__int_as_float(v[i])) : v[i];
+        v[i] = pack_value(T, C, raw);
+    }
+}
+
+/* packed pixel formats: all components share plane, geometry and a pixel pitch of `step` samples;
+ * the n leading positions of v[][], starting at component-plane column x0 of row y */
+__device__ __forceinline__ void pack_store_packed(const PackTile &T, int x0, int y, int n, const int (&v)[4][4])
+{
+    const OutPlanes &O = T.out;
+    const PackComp &C0 = T.c[0];
+    const int ncomp = T.ncomp, step = C0.pix_step, pl = C0.out_plane;
+    const int px = C0.out_x + x0, py = C0.out_y + y;
+    if (py < 0 || py >= O.height[pl] || px < 0) return;
+    const int nvalid = min(n, O.width[pl] - px);
+    if (nvalid <= 0) return;
+    uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)px * step * T.out_bytes;
+    const int nbytes = nvalid * step * T.out_bytes;
+    uint32_t wbuf[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };       /* up to 4 px * 4 comps * 2 bytes */
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c >= step) continue;
+            const int val = (c < ncomp) ? v[c][i] : 0;
+            const int k = i * step + T.c[c < ncomp ? c : 0].pix_off;   /* pix_off == component index for packed formats */
+            if (T.out_bytes == 1) wbuf[k >> 2] |= (uint32_t)(val & 0xFF) << ((k & 3) * 8);
+            else wbuf[k >> 1] |= (uint32_t)(val & 0xFFFF) << ((k & 1) * 16);
+        }
+    if ((((uintptr_t)dst) & 3) == 0 && (nbytes & 3) == 0) {
+        uint32_t *d32 = (uint32_t *)dst;
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+        typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+        if (nbytes == 12) {                                  /* rgb24, 4 pixels: one 12-byte store */
+            u32x3 q; q.x = wbuf[0]; q.y = wbuf[1]; q.z = wbuf[2];
+            *(u32x3_a4 *)d32 = q;
+        } else if (nbytes == 16) {
+            u32x4 q; q.x = wbuf[0]; q.y = wbuf[1]; q.z = wbuf[2]; q.w = wbuf[3];
+            *(u32x4_a4 *)d32 = q;
+        } else {
+            for (int k = 0; k < (nbytes >> 2); k++) d32[k] = wbuf[k];
+        }
+    } else {
+        for (int k = 0; k < nbytes; k++) dst[k] = (uint8_t)(wbuf[k >> 2] >> ((k & 3) * 8));
+    }
+}
+
+/* planar formats: component c on its own plane */
+__device__ __forceinline__ void pack_store_planar(const PackTile &T, int c, int x0, int y, int n, const int (&v)[4])
+{
+    const OutPlanes &O = T.out;
+    const PackComp &C = T.c[c];
+    const int pl = C.out_plane;
+    const int px = C.out_x + x0, py = C.out_y + y;
+    if (py < 0 || py >= O.height[pl] || px < 0) return;
+    const int nvalid = min(n, O.width[pl] - px);
+    if (nvalid <= 0) return;
+    uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)(px * C.pix_step + C.pix_off) * T.out_bytes;
+    if (T.out_bytes == 1) {
+        if (nvalid == 4 && (((uintptr_t)dst) & 3) == 0)
+            *(uint32_t *)dst = (uint32_t)(v[0] & 0xFF) | ((uint32_t)(v[1] & 0xFF) << 8) |
+                               ((uint32_t)(v[2] & 0xFF) << 16) | ((uint32_t)(v[3] & 0xFF) << 24);
+        else
+            for (int i = 0; i < nvalid; i++) dst[i] = (uint8_t)v[i];
+    } else {
+        if (nvalid == 4 && (((uintptr_t)dst) & 7) == 0) {
+            uint2 q;
+            q.x = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)(v[1] & 0xFFFF) << 16);
+            q.y = (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)(v[3] & 0xFFFF) << 16);
+            *(uint2 *)dst = q;
+        } else
+            for (int i = 0; i < nvalid; i++) ((uint16_t *)dst)[i] = (uint16_t)v[i];
+    }
+}
+
+/* One thread = 4 horizontally adjacent sample positions of every component of a tile:
+ * 16-byte plane loads, the inverse MCT in registers, and the packed / planar output row
+ * assembled into whole dwords (rgb24: 12 bytes per thread) instead of byte stores. */
 __global__ void __launch_bounds__(256)
 k_mct_pack(const PackTile *__restrict__ tiles)
 {
     const PackTile &T = tiles[blockIdx.z];
-    const OutPlanes &O = T.out;
+    if (T.fused) return;                                   /* written by the fused final IDWT level */
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x0 >= T.maxw || y >= T.maxh) return;
     const int ncomp = T.ncomp;
@@ -63,6 +176,8 @@ k_mct_pack(const PackTile *__restrict__ tiles)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         cnt[c] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[c][i] = 0;
         if (c >= ncomp) continue;
         const PackComp &C = T.c[c];
         if (x0 >= C.w || y >= C.h) continue;
@@ -79,96 +194,16 @@ k_mct_pack(const PackTile *__restrict__ tiles)
 #pragma unroll
         for (int i = 0; i < 4; i++) v[c][i] = (int)r[i];
     }
-    if (T.mct && cnt[0]) {
-        const int tr = T.c[0].transform;
+    if (T.mct && cnt[0]) pack_mct(T.c[0].transform, v);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t s0 = (uint32_t)v[0][i], s1 = (uint32_t)v[1][i], s2 = (uint32_t)v[2][i];
-            if (tr == J2K_DWT53) {                          /* rct_int, jpeg2000dsp.c:78-91 */
-                const uint32_t i1 = s0 - (uint32_t)((int32_t)(s2 + s1) >> 2);
-                v[0][i] = (int32_t)(i1 + s2); v[1][i] = (int32_t)i1; v[2][i] = (int32_t)(i1 + s1);
-            } else if (tr == J2K_DWT97) {                   /* ict_float, :43-59, then lrintf (jpeg2000dec.c:2340) */
-                const float f0 = __uint_as_float(s0), f1 = __uint_as_float(s1), f2 = __uint_as_float(s2);
-                const float i0f = f0 + (1.402f * f2);
-                const float i1f = f0 - (0.34413f * f1) - (0.71414f * f2);
-                const float i2f = f0 + (1.772f * f1);
-                v[0][i] = __float2int_rn(i0f); v[1][i] = __float2int_rn(i1f); v[2][i] = __float2int_rn(i2f);
-            } else {                                        /* ict_int, :61-76 */
-                const int32_t a0 = (int32_t)s0, a1 = (int32_t)s1, a2 = (int32_t)s2;
-                v[0][i] = a0 + a2 + ((int)((26345U * (uint32_t)a2) + (1 << 15)) >> 16);
-                v[1][i] = a0 - ((int)((22553U * (uint32_t)a1) + (1 << 15)) >> 16)
-                             - ((int)((46802U * (uint32_t)a2) + (1 << 15)) >> 16);
-                v[2][i] = a0 + (2 * a1) + ((int)((-14942U * (uint32_t)a1) + (1 << 15)) >> 16);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        if (!cnt[c]) continue;
-        const PackComp &C = T.c[c];
-        const bool fl = C.transform == J2K_DWT97 && !(T.mct && c < 3);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int raw = fl ? __float2int_rn(__int_as_float(v[c][i])) : v[c][i];
-            v[c][i] = pack_value(T, C, raw);
-        }
-    }
-    /* ---- stores ---- */
-    const PackComp &C0 = T.c[0];
-    const bool packed = C0.pix_step > 1;
-    if (packed) {
-        /* all components share plane, geometry and pixel pitch = ncomp samples */
-        const int n = cnt[0], step = C0.pix_step, pl = C0.out_plane;
-        const int px = C0.out_x + x0, py = C0.out_y + y;
-        if (py < 0 || py >= O.height[pl] || px < 0) return;
-        const int nvalid = min(n, O.width[pl] - px);
-        if (nvalid <= 0) return;
-        uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)px * step * T.out_bytes;
-        const int nbytes = nvalid * step * T.out_bytes;
-        uint32_t wbuf[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };       /* up to 4 px * 4 comps * 2 bytes */
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (c >= step) continue;
-                const int comp = c;                             /* pix_off == component index for packed formats */
-                const int val = (comp < ncomp) ? v[comp][i] : 0;
-                const int k = i * step + T.c[comp < ncomp ? comp : 0].pix_off;
-                if (T.out_bytes == 1) wbuf[k >> 2] |= (uint32_t)(val & 0xFF) << ((k & 3) * 8);
-                else wbuf[k >> 1] |= (uint32_t)(val & 0xFFFF) << ((k & 1) * 16);
-            }
-        if ((((uintptr_t)dst) & 3) == 0 && (nbytes & 3) == 0) {
-            for (int k = 0; k < (nbytes >> 2); k++) ((uint32_t *)dst)[k] = wbuf[k];
-        } else {
-            for (int k = 0; k < nbytes; k++) dst[k] = (uint8_t)(wbuf[k >> 2] >> ((k & 3) * 8));
-        }
+    for (int c = 0; c < 4; c++)
+        if (cnt[c]) pack_convert(T, c, v[c]);
+    if (T.c[0].pix_step > 1) {
+        if (cnt[0]) pack_store_packed(T, x0, y, cnt[0], v);
     } else {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (!cnt[c]) continue;
-            const PackComp &C = T.c[c];
-            const int pl = C.out_plane;
-            const int px = C.out_x + x0, py = C.out_y + y;
-            if (py < 0 || py >= O.height[pl] || px < 0) continue;
-            const int nvalid = min(cnt[c], O.width[pl] - px);
-            if (nvalid <= 0) continue;
-            uint8_t *dst = O.ptr[pl] + (size_t)py * O.linesize[pl] + (size_t)(px * C.pix_step + C.pix_off) * T.out_bytes;
-            if (T.out_bytes == 1) {
-                if (nvalid == 4 && (((uintptr_t)dst) & 3) == 0)
-                    *(uint32_t *)dst = (uint32_t)(v[c][0] & 0xFF) | ((uint32_t)(v[c][1] & 0xFF) << 8) |
-                                       ((uint32_t)(v[c][2] & 0xFF) << 16) | ((uint32_t)(v[c][3] & 0xFF) << 24);
-                else
-                    for (int i = 0; i < nvalid; i++) dst[i] = (uint8_t)v[c][i];
-            } else {
-                if (nvalid == 4 && (((uintptr_t)dst) & 7) == 0) {
-                    uint2 q;
-                    q.x = (uint32_t)(v[c][0] & 0xFFFF) | ((uint32_t)(v[c][1] & 0xFFFF) << 16);
-                    q.y = (uint32_t)(v[c][2] & 0xFFFF) | ((uint32_t)(v[c][3] & 0xFFFF) << 16);
-                    *(uint2 *)dst = q;
-                } else
-                    for (int i = 0; i < nvalid; i++) ((uint16_t *)dst)[i] = (uint16_t)v[c][i];
-            }
-        }
+        for (int c = 0; c < 4; c++)
+            if (cnt[c]) pack_store_planar(T, c, x0, y, cnt[c], v[c]);
     }
 }
 

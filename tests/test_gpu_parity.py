@@ -46,11 +46,13 @@ def test_kats_on_gpu(dec, kat):
     assert st.n_block_errors == 0
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["idwt_generic", "idwt_tile", "idwt_tile2"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4], ids=["idwt_generic", "idwt_tile", "idwt_tile2", "idwt_stream_fused",
+                                                         "idwt_stream_unfused"])
 @pytest.mark.parametrize("name", sorted(streams.CASES))
 def test_frames_match_oracle(dec, orc, name, mode):
     data, kw = streams.get(name)
-    dec.set_int("idwt_mode", mode)
+    dec.set_int("idwt_mode", min(mode, 3))
+    dec.set_int("fuse_pack", 0 if mode == 4 else 1)
     dec.set_int("bitexact", kw.get("bitexact", 0))
     dec.set_int("reduction_factor", kw.get("reduction_factor", 0))
     try:
@@ -59,7 +61,8 @@ def test_frames_match_oracle(dec, orc, name, mode):
     finally:
         dec.set_int("bitexact", 0)
         dec.set_int("reduction_factor", 0)
-        dec.set_int("idwt_mode", 2)
+        dec.set_int("idwt_mode", 3)
+        dec.set_int("fuse_pack", 1)
     assert (info.width, info.height, info.pix_fmt, info.bits_per_raw_sample) == \
            (info_o.width, info_o.height, info_o.pix_fmt, info_o.bits_per_raw_sample)
     assert consumed == consumed_o
@@ -84,7 +87,7 @@ def test_stage_planes_match_oracle(dec, orc, name):
             assert a.dtype == b.dtype
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantised plane %d" % tc
         orc.idwt()
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             dec.set_int("idwt_mode", mode)
             job.run(1).run(2).wait()
             for tc in range(ntc):
@@ -95,7 +98,7 @@ def test_stage_planes_match_oracle(dec, orc, name):
         job.free()
     finally:
         dec.set_int("bitexact", 0)
-        dec.set_int("idwt_mode", 2)
+        dec.set_int("idwt_mode", 3)
 
 
 def test_idwt_random_borders(dec):
@@ -103,7 +106,8 @@ def test_idwt_random_borders(dec):
     borders incl. odd origins, 1..3 sample lines, levels deeper than the size allows"""
     rng = np.random.default_rng(1234)
     cases = [([[151, 170], [140, 183]], 15), ([[1, 4], [1, 3]], 2), ([[5, 6], [3, 20]], 2), ([[0, 1], [0, 1]], 3),
-             ([[1, 2], [1, 2]], 1), ([[0, 2], [0, 2]], 1), ([[3, 6], [2, 4]], 4), ([[0, 257], [1, 130]], 6)]
+             ([[1, 2], [1, 2]], 1), ([[0, 2], [0, 2]], 1), ([[3, 6], [2, 4]], 4), ([[0, 257], [1, 130]], 6),
+             ([[3, 1003], [5, 705]], 3), ([[0, 976], [1, 300]], 2), ([[7, 495], [0, 2]], 1), ([[0, 2], [3, 400]], 2)]
     for _ in range(24):
         x0, y0 = int(rng.integers(0, 40)), int(rng.integers(0, 40))
         cases.append(([[x0, x0 + int(rng.integers(1, 260))], [y0, y0 + int(rng.integers(1, 200))]], int(rng.integers(1, 12))))
@@ -115,11 +119,11 @@ def test_idwt_random_borders(dec):
             else:
                 p = rng.integers(-3000, 3000, (h, w)).astype(np.int32) * (256 if typ == 2 else 1)
             want = oracle.idwt(p, border, lev, typ)
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 dec.set_int("idwt_mode", mode)
                 got = dec.idwt(p, border, lev, typ)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (border, lev, typ, mode)
-    dec.set_int("idwt_mode", 2)
+    dec.set_int("idwt_mode", 3)
 
 
 def test_idwt_53_wraparound(dec):
@@ -128,10 +132,10 @@ def test_idwt_53_wraparound(dec):
     p = rng.integers(-2**31, 2**31 - 1, (70, 90), dtype=np.int64).astype(np.int32)
     border = [[1, 91], [0, 70]]
     want = oracle.idwt(p, border, 3, 1)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         dec.set_int("idwt_mode", mode)
         assert np.array_equal(dec.idwt(p, border, 3, 1), want)
-    dec.set_int("idwt_mode", 2)
+    dec.set_int("idwt_mode", 3)
 
 
 def test_mct_kernels(dec):
