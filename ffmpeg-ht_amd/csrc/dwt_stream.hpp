@@ -72,22 +72,31 @@ template <> struct LiftOps<J2K_DWT97_INT> {
 };
 
 /* horizontal synthesis of the lane's (even, odd, even, odd) quadruple; called with all 64 lanes
- * active.  Afterwards lanes 1..62 hold finished samples. */
+ * active.  Afterwards lanes 1..62 hold finished samples.
+ * mirror_l / mirror_r (fast path): this lane is the first / last one inside a line that starts
+ * on an even position / ends on an odd one.  The symmetric extension makes the odd sample left
+ * of the line the mirror image of the lane's own first odd sample, and the even sample right of
+ * it the image of its own last even sample -- after every lifting step, since the steps are
+ * symmetric -- so the neighbour lane need not hold reflected data. */
 template <int TYPE>
-__device__ __forceinline__ void stream_hlift(uint32_t (&v)[4])
+__device__ __forceinline__ void stream_hlift(uint32_t (&v)[4], bool mirror_l = false, bool mirror_r = false)
 {
     using O = LiftOps<TYPE>;
     uint32_t lo = dpp_from_left(v[3]);
+    if (mirror_l) lo = v[1];
     v[0] = O::s1(v[0], lo, v[1]);
     v[2] = O::s1(v[2], v[1], v[3]);
     uint32_t re = dpp_from_right(v[0]);
+    if (mirror_r) re = v[2];
     v[1] = O::s2(v[1], v[0], v[2]);
     v[3] = O::s2(v[3], v[2], re);
     if (TYPE != J2K_DWT53) {
         lo = dpp_from_left(v[3]);
+        if (mirror_l) lo = v[1];
         v[0] = O::s3(v[0], lo, v[1]);
         v[2] = O::s3(v[2], v[1], v[3]);
         re = dpp_from_right(v[0]);
+        if (mirror_r) re = v[2];
         v[1] = O::s4(v[1], v[0], v[2]);
         v[3] = O::s4(v[3], v[2], re);
     }
@@ -102,9 +111,17 @@ struct DwtFusedArgs {
     int32_t pad;
 };
 
-template <int TYPE, int NC, bool FUSED>
+/* FAST (chosen per wave, see idwt_stream_body): the line starts on an even position and its
+ * length is a multiple of 4, so every lane is either wholly inside the line or wholly outside;
+ * loads are unconditional 8-byte loads (columns of outside lanes are clamped, the two values
+ * that cross the line ends come from the mirror rule of stream_hlift), stores are one
+ * predicated 16-byte (plain) or 12-byte (rgb24) store per row, and nothing in the loop body
+ * has a data-dependent trip count: the compiler can then keep the next step's loads in
+ * flight across the current step (s_waitcnt vmcnt(N > 0)).  FAST && FUSED is the rgb24 case:
+ * three 8-bit components on one packed plane. */
+template <int TYPE, int NC, bool FUSED, bool FAST>
 __device__ __forceinline__ void
-idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
+idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th)
 {
     using O = LiftOps<TYPE>;
@@ -118,14 +135,21 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     /* ---- columns of this lane ---- */
     const int ax0 = (g.mh + x0 - 4) & ~1;                 /* even; lane 1 starts at or one before the strip */
     const int pe0 = ax0 + 4 * lane;
-    const bool interior = ax0 >= g.mh && ax0 + 256 <= g.mh + g.lh;      /* wave-uniform: no reflection, all loaded */
+    const bool interior = ax0 >= g.mh && ax0 + 256 <= g.mh + g.lh;      /* wave-uniform: no reflection, 8-byte loads */
+    /* storage columns; positions outside the line go through the reflection, so every load
+     * address is valid and no load is predicated (results further than HALO + 2 outside the
+     * line are never used) */
     int col[4];
-    bool use[4];
+    bool mirror_l = false, mirror_r = false;
+    if (FAST) {
+        const int q = (pe0 - g.mh) >> 1;                  /* pair index of (e0, o0); g.mh is even */
+        const int qc = min(max(q, 0), LX.nl - 2);         /* lanes outside the line: any valid address */
+        col[0] = qc; col[2] = qc + 1; col[1] = LX.nl + qc; col[3] = col[1] + 1;
+        mirror_l = pe0 == g.mh;
+        mirror_r = pe0 + 4 == g.mh + g.lh;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int p = pe0 + k;
-        use[k] = p >= g.mh - HALO - 2 && p < g.mh + g.lh + HALO + 2;
-        col[k] = use[k] ? LX.idx(p) : 0;
+        for (int k = 0; k < 4; k++) col[k] = LX.idx(pe0 + k);
     }
     const uint32_t *llp[NC], *bandp[NC];
 #pragma unroll
@@ -139,30 +163,39 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     const int s_first = (a_first - HALO) & ~1;
     const int s_last = (a_last + DELAY + 1) & ~1;
 
+    /* The loads of a step: unconditional and the same number on every pass of the loop, so
+     * that the compiler can wait for exactly the older step's loads (s_waitcnt vmcnt(N)) while
+     * the newer step's are in flight. */
     auto load_rows = [&](int ye, uint32_t (&Lr)[NC][4], uint32_t (&Hr)[NC][4]) {
+        int iy[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int ay = ye + r;
-            const bool rowok = ay >= g.mv - HALO - 2 && ay < g.mv + g.lv + HALO + 2;
-            int iy = 0;
-            if (rowok)
-                iy = (ay >= LY.i0 && ay < LY.i1) ? ((ay & 1) ? LY.nl + ((ay - LY.fo) >> 1) : ((ay - LY.fe) >> 1)) : LY.idx(ay);
+            const int ay = min(ye, s_last) + r;             /* the one prefetch past the strip re-reads its last rows */
+            iy[r] = (ay >= LY.i0 && ay < LY.i1) ? ((ay & 1) ? LY.nl + ((ay - LY.fo) >> 1) : ((ay - LY.fe) >> 1)) : LY.idx(ay);
+        }
+        /* even absolute rows are vertical-low rows (the reflection keeps the parity): their
+         * low-horizontal half is the previous level's output */
+        if (FAST || interior) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                uint32_t (&dstv)[4] = r ? Hr[c] : Lr[c];
-                /* even absolute rows are vertical-low rows (reflection keeps the parity): their
-                 * low-horizontal half is the previous level's output */
-                const uint32_t *orow = bandp[c] + (size_t)iy * A[c].g.stride;
-                const uint32_t *erow = r ? orow : llp[c] + (size_t)iy * A[c].ll_stride;
-                if (!rowok) {
-                    dstv[0] = dstv[1] = dstv[2] = dstv[3] = 0;
-                } else if (interior) {
-                    const uint2 e = *(const uint2 *)(erow + col[0]);
-                    const uint2 o = *(const uint2 *)(orow + col[1]);
-                    dstv[0] = e.x; dstv[1] = o.x; dstv[2] = e.y; dstv[3] = o.y;
-                } else {
+                const uint32_t *lrow = llp[c] + (size_t)iy[0] * A[c].ll_stride;
+                const uint32_t *brow0 = bandp[c] + (size_t)iy[0] * A[c].g.stride;
+                const uint32_t *brow1 = bandp[c] + (size_t)iy[1] * A[c].g.stride;
+                const uint2 le = *(const uint2 *)(lrow + col[0]), lo = *(const uint2 *)(brow0 + col[1]);
+                const uint2 he = *(const uint2 *)(brow1 + col[0]), ho = *(const uint2 *)(brow1 + col[1]);
+                Lr[c][0] = le.x; Lr[c][1] = lo.x; Lr[c][2] = le.y; Lr[c][3] = lo.y;
+                Hr[c][0] = he.x; Hr[c][1] = ho.x; Hr[c][2] = he.y; Hr[c][3] = ho.y;
+            }
+        } else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) dstv[k] = use[k] ? ((k & 1) ? orow : erow)[col[k]] : 0u;
+            for (int c = 0; c < NC; c++) {
+                const uint32_t *lrow = llp[c] + (size_t)iy[0] * A[c].ll_stride;
+                const uint32_t *brow0 = bandp[c] + (size_t)iy[0] * A[c].g.stride;
+                const uint32_t *brow1 = bandp[c] + (size_t)iy[1] * A[c].g.stride;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    Lr[c][k] = ((k & 1) ? brow0 : lrow)[col[k]];
+                    Hr[c][k] = brow1[col[k]];
                 }
             }
         }
@@ -187,9 +220,75 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     }
     const bool full = ia == 0 && ib == 4;
 
-    auto emit = [&](int row_abs, uint32_t (&val)[NC][4]) {
+    /* fast fused path: frame geometry and per-component conversion constants in scalars */
+    uint8_t *f_dst = nullptr;
+    int f_ls = 0, f_dc[3] = { 0, 0, 0 }, f_hi[3] = { 0, 0, 0 }, f_sh[3] = { 0, 0, 0 };
+    bool f_mct = false;
+    if (FAST && FUSED) {
+        const PackComp &C0 = T->c[0];
+        f_ls = T->out.linesize[C0.out_plane];
+        f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * 3;
+        f_mct = T->mct != 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            f_dc[c] = 1 << (T->c[c].cbps - 1);
+            f_hi[c] = (1 << T->c[c].cbps) - 1;
+            f_sh[c] = T->precision - T->c[c].cbps;
+        }
+    }
+    const bool lane_ok = lane >= 1 && xa + 4 <= x_hi;     /* FAST: the quadruple is wholly inside the strip */
+
+    uint32_t wk[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };       /* fast fused path: the two rows' store data ... */
+    uintptr_t ak[2] = { 0, 0 };                              /* ... and addresses of the last step */
+    auto emit = [&](int row_abs, uint32_t (&val)[NC][4], int slot) {
         const int y = row_abs - g.mv;
         if (row_abs < a_first || row_abs > a_last) return;                 /* wave-uniform */
+        if (FAST) {
+            if (TYPE == J2K_DWT97_INT && g.last) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) val[c][k] = (uint32_t)((int32_t)((int32_t)val[c][k] + 128) >> 8);   /* :534-536 */
+            }
+            if (!FUSED) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    uint32_t *p = out_base + A[c].out_off + (size_t)y * A[c].out_stride + xa;
+                    if (lane_ok) *(uint4 *)p = make_uint4(val[c][0], val[c][1], val[c][2], val[c][3]);
+                }
+            } else {
+                int v[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[c][k] = c < NC ? (int)val[c < NC ? c : 0][k] : 0;
+                if (f_mct) {
+                    pack_mct(TYPE, v);
+                } else if (TYPE == J2K_DWT97) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[c][k] = __float2int_rn(__int_as_float(v[c][k]));
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[c][k] = min(max(v[c][k] + f_dc[c], 0), f_hi[c]) << f_sh[c];
+                /* the frame pointer comes out of a descriptor: say that it is global memory, or the
+                 * store is a FLAT one (slower, and the compiler then waits vmcnt(0) everywhere) */
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+                typedef __attribute__((address_space(1))) u32x3_a4 g_u32x3;
+                u32x3 w;
+                w.x = (uint32_t)v[0][0] | ((uint32_t)v[1][0] << 8) | ((uint32_t)v[2][0] << 16) | ((uint32_t)v[0][1] << 24);
+                w.y = (uint32_t)v[1][1] | ((uint32_t)v[2][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[1][2] << 24);
+                w.z = (uint32_t)v[2][2] | ((uint32_t)v[0][3] << 8) | ((uint32_t)v[1][3] << 16) | ((uint32_t)v[2][3] << 24);
+                const uintptr_t addr = (uintptr_t)(f_dst + (size_t)y * f_ls);
+                if (lane_ok) *(g_u32x3 *)addr = w;
+                wk[slot][0] = w.x; wk[slot][1] = w.y; wk[slot][2] = w.z; ak[slot] = addr;
+            }
+            return;
+        }
         if (ib <= ia) return;
         if (TYPE == J2K_DWT97_INT && g.last) {
 #pragma unroll
@@ -244,15 +343,12 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         }
     };
 
-    uint32_t Lc[NC][4], Hc[NC][4], Ln[NC][4], Hn[NC][4];
-    load_rows(s_first, Lc, Hc);
-    for (int ye = s_first; ye <= s_last; ye += 2) {
-        if (ye + 2 <= s_last) load_rows(ye + 2, Ln, Hn);
+    auto step = [&](int ye, uint32_t (&Lc)[NC][4], uint32_t (&Hc)[NC][4]) {
         uint32_t r_odd[NC][4], r_even[NC][4];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            stream_hlift<TYPE>(Lc[c]);
-            stream_hlift<TYPE>(Hc[c]);
+            stream_hlift<TYPE>(Lc[c], mirror_l, mirror_r);
+            stream_hlift<TYPE>(Hc[c], mirror_l, mirror_r);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (TYPE == J2K_DWT53) {
@@ -270,13 +366,67 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 }
             }
         }
-        emit(ye - DELAY - 1, r_odd);
-        emit(ye - DELAY, r_even);
+        emit(ye - DELAY - 1, r_odd, 0);
+        emit(ye - DELAY, r_even, 1);
+    };
+
+    /* two register buffers, loop unrolled by two: the loads of step s + 1 are in flight while
+     * step s computes and stores */
+    uint32_t LA[NC][4], HA[NC][4], LB[NC][4], HB[NC][4];
+    load_rows(s_first, LA, HA);
+    /* an empty asm that "rewrites" the older buffer and clobbers memory: the newer buffer's loads
+     * cannot sink below it and the older buffer's arithmetic cannot rise above it, so the loads
+     * really are issued a whole step ahead (the instruction scheduler otherwise interleaves them
+     * with the arithmetic they were meant to overlap) */
+    auto pin = [&](uint32_t (&Lr)[NC][4], uint32_t (&Hr)[NC][4]) {
 #pragma unroll
         for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) { Lc[c][k] = Ln[c][k]; Hc[c][k] = Hn[c][k]; }
+            asm volatile("" : "+v"(Lr[c][0]), "+v"(Lr[c][1]), "+v"(Lr[c][2]), "+v"(Lr[c][3]),
+                              "+v"(Hr[c][0]), "+v"(Hr[c][1]), "+v"(Hr[c][2]), "+v"(Hr[c][3]) : : "memory");
+        /* the registers of the last step's store data stay allocated until the next loads are
+         * out: rewriting them earlier costs a wait for those stores (and, vmcnt being in order,
+         * for every load issued before them) */
+        if (FAST && FUSED)
+            asm volatile("" : : "v"(wk[0][0]), "v"(wk[0][1]), "v"(wk[0][2]), "v"(wk[1][0]), "v"(wk[1][1]), "v"(wk[1][2]),
+                                "v"(ak[0]), "v"(ak[1]));
+    };
+    for (int ye = s_first;; ye += 4) {
+        load_rows(ye + 2, LB, HB);
+        pin(LA, HA);
+        step(ye, LA, HA);
+        if (ye + 2 > s_last) break;
+        load_rows(ye + 4, LA, HA);
+        pin(LB, HB);
+        step(ye + 2, LB, HB);
+        if (ye + 4 > s_last) break;
     }
+}
+
+/* per-wave choice of the fast path (all conditions are wave-uniform) */
+template <int TYPE, int NC, bool FUSED>
+__device__ __forceinline__ void
+idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th)
+{
+    const DwtLevel &g = A[0].g;
+    bool fast = !(g.mh & 1) && !(g.lh & 3) && g.lh >= 8;
+    if (FUSED) {
+        if (NC != 3) {
+            fast = false;
+        } else {
+            const PackComp &C0 = T->c[0];
+            const OutPlanes &O = T->out;
+            const int pl = C0.out_plane;
+            fast = fast && T->ncomp == 3 && T->out_bytes == 1 && C0.pix_step == 3 && comp0 == 0 &&
+                   T->c[0].pix_off == 0 && T->c[1].pix_off == 1 && T->c[2].pix_off == 2 &&
+                   T->precision == 8 && T->c[0].cbps <= 8 && T->c[1].cbps <= 8 && T->c[2].cbps <= 8 &&
+                   C0.out_x >= 0 && !(C0.out_x & 3) && C0.out_y >= 0 &&
+                   C0.out_x + g.lh <= O.width[pl] && C0.out_y + g.lv <= O.height[pl] &&
+                   !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
+        }
+    }
+    if (fast) idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th);
+    else idwt_stream_impl<TYPE, NC, FUSED, false>(A, ll_base, band_base, out_base, T, comp0, th);
 }
 
 /* plain level: grid.z indexes the DwtTileArgs table (one plane each), blockDim = one wave */
