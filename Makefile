@@ -21,7 +21,7 @@ $(CSRC)/j2k_parse.o: $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h include/htj2k_amd.h
 # -ffp-contract=off: the reference objects contain no FMA; 9/7 parity needs
 # separately rounded multiply and add.
 $(CSRC)/htj2k_device.o: $(CSRC)/htj2k_device.hip $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h include/htj2k_amd.h $(wildcard $(CSRC)/*.hpp)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -g -fPIC -ffp-contract=off -std=c++17 -Wall -c $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -g -fPIC -ffp-contract=off -std=c++17 -Wall $(HIPFLAGS_EXTRA) -c $< -o $@
 
 $(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/j2k_parse.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread

@@ -76,7 +76,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
            "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
-           "htj2k_job_idwt_launches"]
+           "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes"]
 
 _lib = None
 
@@ -150,6 +150,12 @@ class Job:
         by = (ctypes.c_double * cap)()
         n = _check(self.dec.L.htj2k_job_idwt_launches(self.dec.h, self.h, ms, by, cap), "htj2k_job_idwt_launches")
         return [(ms[i], by[i]) for i in range(min(n, cap))]
+
+    def idwt_hbm_bytes(self, cap=256):
+        """least HBM bytes of the same launches (differs from the algorithmic figure for a fused final level)"""
+        by = (ctypes.c_double * cap)()
+        n = _check(self.dec.L.htj2k_job_idwt_hbm_bytes(self.dec.h, self.h, by, cap), "htj2k_job_idwt_hbm_bytes")
+        return [by[i] for i in range(min(n, cap))]
 
     def upload(self):
         _check(self.dec.L.htj2k_job_upload(self.dec.h, self.h), "htj2k_job_upload")

@@ -122,12 +122,12 @@ struct DwtFusedArgs {
 template <int TYPE, int NC, bool FUSED, bool FAST>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
-                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th)
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
 {
     using O = LiftOps<TYPE>;
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
     const DwtLevel g = A[0].g;
-    const int x0 = blockIdx.x * STREAM_TW, y0 = blockIdx.y * th;
+    const int x0 = bx * STREAM_TW, y0 = by * th;
     if (x0 >= g.lh || y0 >= g.lv) return;
     const LineMap LX(g.mh, g.lh), LY(g.mv, g.lv);
     const int lane = threadIdx.x;
@@ -402,54 +402,86 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     }
 }
 
-/* per-wave choice of the fast path (all conditions are wave-uniform) */
-template <int TYPE, int NC, bool FUSED>
+/* Which waves may take the fast path: conditions on the level geometry and, for the fused
+ * kernel, on the frame it writes.  The host evaluates the same predicates per launch: when every
+ * entry of a launch qualifies it starts the FASTONLY kernels, which do not carry the general
+ * path's registers (126 instead of 172 VGPRs for 5/3 rgb24: 4 instead of 2 waves per SIMD). */
+__host__ __device__ inline bool stream_fast_geom(const DwtLevel &g)
+{
+    return !(g.mh & 1) && !(g.lh & 3) && g.lh >= 8 && g.lv >= 2;
+}
+__host__ __device__ inline bool stream_fast_rgb24(const PackTile &T, const DwtLevel &g, int ncomp_group, int comp0)
+{
+    const PackComp &C0 = T.c[0];
+    const OutPlanes &O = T.out;
+    const int pl = C0.out_plane;
+    return ncomp_group == 3 && T.ncomp == 3 && T.out_bytes == 1 && C0.pix_step == 3 && comp0 == 0 &&
+           T.c[0].pix_off == 0 && T.c[1].pix_off == 1 && T.c[2].pix_off == 2 &&
+           T.precision == 8 && T.c[0].cbps <= 8 && T.c[1].cbps <= 8 && T.c[2].cbps <= 8 &&
+           C0.out_x >= 0 && !(C0.out_x & 3) && C0.out_y >= 0 &&
+           C0.out_x + g.lh <= O.width[pl] && C0.out_y + g.lv <= O.height[pl] &&
+           !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
+}
+
+template <int TYPE, int NC, bool FUSED, bool FASTONLY>
 __device__ __forceinline__ void
 idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
-                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th)
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
 {
-    const DwtLevel &g = A[0].g;
-    bool fast = !(g.mh & 1) && !(g.lh & 3) && g.lh >= 8;
-    if (FUSED) {
-        if (NC != 3) {
-            fast = false;
-        } else {
-            const PackComp &C0 = T->c[0];
-            const OutPlanes &O = T->out;
-            const int pl = C0.out_plane;
-            fast = fast && T->ncomp == 3 && T->out_bytes == 1 && C0.pix_step == 3 && comp0 == 0 &&
-                   T->c[0].pix_off == 0 && T->c[1].pix_off == 1 && T->c[2].pix_off == 2 &&
-                   T->precision == 8 && T->c[0].cbps <= 8 && T->c[1].cbps <= 8 && T->c[2].cbps <= 8 &&
-                   C0.out_x >= 0 && !(C0.out_x & 3) && C0.out_y >= 0 &&
-                   C0.out_x + g.lh <= O.width[pl] && C0.out_y + g.lv <= O.height[pl] &&
-                   !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
-        }
+    if (FASTONLY) {
+        idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+    } else {                                               /* per-wave choice; all conditions are wave-uniform */
+        bool fast = stream_fast_geom(A[0].g);
+        if (FUSED) fast = fast && stream_fast_rgb24(*T, A[0].g, NC, comp0);
+        if (fast) idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+        else idwt_stream_impl<TYPE, NC, FUSED, false>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
     }
-    if (fast) idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th);
-    else idwt_stream_impl<TYPE, NC, FUSED, false>(A, ll_base, band_base, out_base, T, comp0, th);
 }
 
-/* plain level: grid.z indexes the DwtTileArgs table (one plane each), blockDim = one wave */
-template <int TYPE>
+/* XCD-aware order of the strips.  The launch is a 1-D grid of 8 * per_xcd workgroups, which the
+ * hardware deals out to the 8 XCDs round-robin (workgroup b -> XCD b % 8).  Strip number
+ * (b % 8) * per_xcd + b / 8 then gives every XCD one contiguous run of strips in (x fastest, y,
+ * table entry) order: column strips that share cache lines at their edges (a wave loads 512 bytes
+ * per sub-band row of which 488 are its own, and 244-sample strips are not line-aligned) and row
+ * strips that share HALO rows meet in the same L2 instead of fetching those lines once per XCD. */
+struct StreamGrid { int gx, gy, nstrips, per_xcd; };
+__device__ __forceinline__ bool stream_strip(const StreamGrid &G, int &bx, int &by, int &bz)
+{
+    const int b = blockIdx.x;
+    const int s = (b & 7) * G.per_xcd + (b >> 3);
+    if (s >= G.nstrips) return false;
+    bx = s % G.gx;
+    const int t = s / G.gx;
+    by = t % G.gy;
+    bz = t / G.gy;
+    return true;
+}
+
+/* plain level: one DwtTileArgs table entry per plane, blockDim = one wave */
+template <int TYPE, bool FASTONLY>
 __global__ void __launch_bounds__(64)
 k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
-              const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th)
+              const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G)
 {
-    const DwtTileArgs A[1] = { args[blockIdx.z] };
-    idwt_stream_body<TYPE, 1, false>(A, ll_base, band_base, out_base, nullptr, 0, th);
+    int bx, by, bz;
+    if (!stream_strip(G, bx, by, bz)) return;
+    const DwtTileArgs A[1] = { args[bz] };
+    idwt_stream_body<TYPE, 1, false, FASTONLY>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by);
 }
 
-/* final level + inverse MCT + frame store: grid.z indexes the DwtFusedArgs table */
-template <int TYPE, int NC>
+/* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
+template <int TYPE, int NC, bool FASTONLY>
 __global__ void __launch_bounds__(64)
 k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
-                   const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th)
+                   const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th, StreamGrid G)
 {
-    const DwtFusedArgs &F = args[blockIdx.z];
+    int bx, by, bz;
+    if (!stream_strip(G, bx, by, bz)) return;
+    const DwtFusedArgs &F = args[bz];
     DwtTileArgs A[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) A[c] = F.a[c];
-    idwt_stream_body<TYPE, NC, true>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th);
+    idwt_stream_body<TYPE, NC, true, FASTONLY>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
 }
 
 }  // namespace htj2k

@@ -67,9 +67,11 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
     int count;                         /* planes */
     size_t table_off;                  /* byte offset of its DwtLevel / DwtTileArgs table in d_desc */
     int max_lh, max_lv, min_l;         /* min_l: smallest line length of any plane (1-sample lines need k_idwt_tile) */
-    double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv; fused final level:
-                                        * 4 * lh * lv read + the frame bytes written */
+    double alg_bytes;                  /* sum over its planes of 2 * 4 * lh * lv */
+    double hbm_bytes = 0;              /* least HBM traffic: alg_bytes, or for a fused final level 4 * lh * lv read +
+                                        * the frame bytes written */
     int nc = 0;                        /* 0: table of DwtTileArgs; 1/3/4: table of DwtFusedArgs (fused final level) */
+    bool all_fast = false;             /* every entry qualifies for the streaming kernels' fast path */
 };
 
 struct FrameSlot {                     /* one frame of a batch */
@@ -94,7 +96,7 @@ struct htj2k_job {
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     std::vector<hipEvent_t> lev_ev;    /* per-IDWT-launch brackets (roofline measurement) */
     int lev_ev_used = 0;
-    std::vector<double> lev_bytes;     /* algorithmic bytes of each recorded launch */
+    std::vector<double> lev_bytes, lev_hbm;   /* algorithmic / least-HBM bytes of each recorded launch */
     DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_msu, d_vlcu, d_melu;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     size_t nquads = 0;
@@ -450,6 +452,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
         for (int type = 0; type < 3; type++) {
             LevelLaunch g;
             g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0; g.min_l = 1 << 30;
+            g.all_fast = true;
             std::vector<DwtLevel> lv;
             std::vector<DwtTileArgs> ta;
             for (int t = 0; t < ntc; t++) {
@@ -472,6 +475,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                 if (d.lh < g.min_l) g.min_l = d.lh;
                 if (d.lv < g.min_l) g.min_l = d.lv;
                 g.alg_bytes += 8.0 * d.lh * d.lv;
+                g.all_fast = g.all_fast && stream_fast_geom(d);
             }
             if (lv.empty()) continue;
             g.count = (int)lv.size();
@@ -603,6 +607,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
             for (int type = 0; type < 3; type++) {
                 LevelLaunch g;
                 g.type = type; g.level = lev; g.count = 0; g.max_lh = g.max_lv = 0; g.alg_bytes = 0; g.min_l = 1 << 30; g.nc = 0;
+                g.all_fast = true;
                 std::vector<DwtTileArgs> ta;
                 for (int t = 0; t < ntc; t++) {
                     const J2kTileComp &tc = j->tilecomps[t];
@@ -613,6 +618,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                     g.max_lh = std::max(g.max_lh, a.g.lh); g.max_lv = std::max(g.max_lv, a.g.lv);
                     g.min_l = std::min(g.min_l, std::min(a.g.lh, a.g.lv));
                     g.alg_bytes += 8.0 * a.g.lh * a.g.lv;
+                    g.all_fast = g.all_fast && stream_fast_geom(a.g);
                 }
                 if (!ta.empty()) {
                     g.count = (int)ta.size();
@@ -623,7 +629,8 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                 }
                 for (int nc = 1; nc <= 4; nc++) {
                     LevelLaunch fz = g;
-                    fz.count = 0; fz.max_lh = fz.max_lv = 0; fz.alg_bytes = 0; fz.min_l = 1 << 30; fz.nc = nc;
+                    fz.count = 0; fz.max_lh = fz.max_lv = 0; fz.alg_bytes = 0; fz.hbm_bytes = 0; fz.min_l = 1 << 30; fz.nc = nc;
+                    fz.all_fast = true;
                     std::vector<DwtFusedArgs> fa;
                     for (const Group &gr : groups) {
                         const J2kTileComp &tc = j->tilecomps[gr.tc0];
@@ -636,7 +643,9 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                         fz.max_lh = std::max(fz.max_lh, A.a[0].g.lh); fz.max_lv = std::max(fz.max_lv, A.a[0].g.lv);
                         fz.min_l = std::min(fz.min_l, std::min(A.a[0].g.lh, A.a[0].g.lv));
                         const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + gr.pack_tile;
-                        fz.alg_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * (4.0 + PT->out_bytes);
+                        fz.alg_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * 8.0;
+                        fz.hbm_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * (4.0 + PT->out_bytes);
+                        fz.all_fast = fz.all_fast && stream_fast_geom(A.a[0].g) && stream_fast_rgb24(*PT, A.a[0].g, nc, gr.comp0);
                     }
                     if (fa.empty()) continue;
                     fz.count = (int)fa.size();
@@ -749,26 +758,38 @@ static void launch_generic_level(htj2k_job *j, const LevelLaunch &L)
 #define TILE_W 64
 #define TILE_H 32
 
-/* rows per wave of the streaming kernels: enough strips to put several waves on every SIMD
- * (1024 SIMDs), long enough that the HALO rows re-read per strip stay a few percent */
+/* rows per wave of the streaming kernels.  Measured on the 4K batch (tools/gpu_strip.py): the
+ * launches are bound by the memory pipeline, not by the HALO rows a strip re-reads (those hit in
+ * the XCD's L2, see stream_strip()), and 12..18 rows per strip is the flat optimum -- many short
+ * waves keep more loads in flight and leave a shorter tail than few long ones. */
 static int stream_strip_rows(int max_lh, int max_lv, int count)
 {
-    const long cols = (max_lh + STREAM_TW - 1) / STREAM_TW;
     const char *e = getenv("HTJ2K_STRIP");
     if (e && atoi(e) >= 8) return atoi(e) & ~1;
-    int th = 128;
-    while (th > 16 && cols * ((max_lv + th - 1) / th) * count < 6144) th >>= 1;
-    return th;
+    const long cols = (max_lh + STREAM_TW - 1) / STREAM_TW;
+    return cols * ((max_lv + 15) / 16) * count >= 2048 ? 16 : 8;
+}
+
+static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count)
+{
+    StreamGrid G;
+    G.gx = (max_lh + STREAM_TW - 1) / STREAM_TW;
+    G.gy = (max_lv + th - 1) / th;
+    G.nstrips = G.gx * G.gy * count;
+    G.per_xcd = (G.nstrips + 7) / 8;
+    return G;
 }
 
 template <int TYPE>
 static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min_l, int count, int mode, hipStream_t s,
-                                const uint32_t *ll, const uint32_t *band, uint32_t *out)
+                                const uint32_t *ll, const uint32_t *band, uint32_t *out, bool all_fast)
 {
     if (mode >= 3 && min_l >= 2) {
         const int th = stream_strip_rows(max_lh, max_lv, count);
-        dim3 g((max_lh + STREAM_TW - 1) / STREAM_TW, (max_lv + th - 1) / th, count);
-        hipLaunchKernelGGL((k_idwt_stream<TYPE>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th);
+        const StreamGrid G = stream_grid(max_lh, max_lv, th, count);
+        dim3 g(8 * G.per_xcd);
+        if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        else hipLaunchKernelGGL((k_idwt_stream<TYPE, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
     } else if (mode >= 2 && min_l >= 2) {
         constexpr int TW2 = 128 - 2 * Lift<TYPE>::HALO - 2, TH2 = 64;
         dim3 g((max_lh + TW2 - 1) / TW2, (max_lv + TH2 - 1) / TH2, count);
@@ -783,20 +804,22 @@ template <int TYPE>
 static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
 {
     launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
-                              j->stream, ll, (const uint32_t *)j->d_coef.p, out);
+                              j->stream, ll, (const uint32_t *)j->d_coef.p, out, L.all_fast);
 }
 
 template <int TYPE>
 static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll)
 {
     const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
-    dim3 g((L.max_lh + STREAM_TW - 1) / STREAM_TW, (L.max_lv + th - 1) / th, L.count);
+    const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count);
+    dim3 g(8 * G.per_xcd);
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
-    if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
-    else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
-    else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th);
+    if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
 }
 
 static hipEvent_t lev_event(htj2k_job *j)
@@ -813,6 +836,7 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
 {
     j->lev_ev_used = 0;
     j->lev_bytes.clear();
+    j->lev_hbm.clear();
     const std::vector<LevelLaunch> &LL = fuse ? j->launches_fused : use_tile ? j->launches_tile : j->launches_generic;
     for (const LevelLaunch &L : LL) {
         hipEvent_t e0 = lev_event(j);
@@ -836,6 +860,7 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
         hipEvent_t e1 = lev_event(j);
         if (e1) (void)hipEventRecord(e1, j->stream);
         j->lev_bytes.push_back(L.alg_bytes);
+        j->lev_hbm.push_back(L.nc ? L.hbm_bytes : L.alg_bytes);
     }
     return 0;
 }
@@ -965,6 +990,15 @@ extern "C" int htj2k_job_idwt_launches(htj2k_ctx *c, htj2k_job *j, float *ms, do
     return n;
 }
 
+extern "C" int htj2k_job_idwt_hbm_bytes(htj2k_ctx *c, htj2k_job *j, double *bytes, int cap)
+{
+    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    const int n = (int)j->lev_hbm.size();
+    for (int i = 0; i < n && i < cap; i++)
+        if (bytes) bytes[i] = j->lev_hbm[i];
+    return n;
+}
+
 extern "C" int htj2k_job_block_errors(htj2k_ctx *c, htj2k_job *j)
 {
     if (!c || !j || j->nframes <= 0) return HTJ2K_ERR_EINVAL;
@@ -1070,6 +1104,7 @@ struct PlaneSet {                 /* nplanes identical-geometry planes laid out 
     size_t plane_samples;
     std::vector<std::vector<uint8_t>> tables_generic, tables_tile;   /* per level */
     std::vector<int> lh, lv;
+    std::vector<uint8_t> fast;        /* per level: stream_fast_geom */
 };
 
 static void planeset_build(PlaneSet &P, const int border[2][2], int levels, int type, int nplanes)
@@ -1092,6 +1127,11 @@ static void planeset_build(PlaneSet &P, const int border[2][2], int levels, int 
         }
         P.tables_generic.push_back(tg); P.tables_tile.push_back(tt);
         P.lh.push_back(linelen[lev][0]); P.lv.push_back(linelen[lev][1]);
+        {
+            DwtLevel d;
+            d.plane_off = 0; d.stride = P.w; d.lh = linelen[lev][0]; d.lv = linelen[lev][1]; d.mh = mod[lev][0]; d.mv = mod[lev][1]; d.last = 0;
+            P.fast.push_back(stream_fast_geom(d));
+        }
     }
 }
 
@@ -1107,7 +1147,7 @@ static void planeset_launch_level(const PlaneSet &P, int lev, int mode, int kth,
         const uint32_t *ll = kth == 0 ? coef : ((kth - 1) & 1) ? t1 : t0;
         uint32_t *out = (kth & 1) ? t1 : t0;
         launch_tile_generic<TYPE>(d_tab, P.lh[lev], P.lv[lev], P.lh[lev] < P.lv[lev] ? P.lh[lev] : P.lv[lev], P.nplanes, mode, s,
-                                  ll, (const uint32_t *)coef, out);
+                                  ll, (const uint32_t *)coef, out, P.fast[lev] != 0);
     }
 }
 

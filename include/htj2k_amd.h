@@ -141,9 +141,13 @@ int  htj2k_job_parse_batch(htj2k_ctx *ctx, const uint8_t *const *pkts, const int
 int  htj2k_job_num_frames(const htj2k_job *job);
 int  htj2k_job_frame_info(const htj2k_job *job, int frame, htj2k_info *info);
 int  htj2k_job_download_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
-/* per-launch device time (ms) and algorithmic bytes of the IDWT kernels of the last run;
- * returns the number of launches */
+/* per-launch device time (ms) and algorithmic bytes (2 * 4 * lh * lv per plane and level, one
+ * read + one write of every sample) of the IDWT kernels of the last run; returns the number of
+ * launches.  htj2k_job_idwt_hbm_bytes() gives, for the same launches, the bytes the kernel has
+ * to move through HBM at least: the same figure for a plain level, 4 * lh * lv + the frame bytes
+ * written for a final level that is fused with the MCT / pack stage. */
 int  htj2k_job_idwt_launches(htj2k_ctx *ctx, htj2k_job *job, float *ms, double *bytes, int cap);
+int  htj2k_job_idwt_hbm_bytes(htj2k_ctx *ctx, htj2k_job *job, double *bytes, int cap);
 /* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
 int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
 /* device: HT block decode + dequant -> IDWT -> MCT/level shift/clip/pack (async) */
