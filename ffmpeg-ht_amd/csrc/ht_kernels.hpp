@@ -202,6 +202,42 @@ __device__ __forceinline__ uint32_t ht_dpp_right(uint32_t v)       /* lane i <- 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
 }
 
+/* MagSgn bytes -> plain LSB-first bit array in LDS (jpeg2000htdec.c:207-221): a byte that follows
+ * 0xFF advances the stream by 7 bits but is ORed in whole.  Four bytes per lane and pass: the
+ * lane's bytes are merged into one chunk of 28..32 stream bits, a wave prefix sum of the chunk
+ * lengths gives its bit offset, two ds_or place it.  D is 16-byte aligned (j2k_parse.c lays the
+ * block data out that way); ms[] must be zero up to the word after the last stream bit.
+ * Returns the number of stream bits. */
+__device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict__ D, uint32_t Pcup, uint32_t *ms, int lane)
+{
+    const uint32_t *Dw = (const uint32_t *)D;
+    uint32_t base = 0, carry = 0;                          /* carry: the last byte of the previous pass */
+    for (uint32_t w0 = 0; w0 * 4 < Pcup; w0 += 64) {
+        const uint32_t wi = w0 + lane;
+        const int nv = min(max((int)Pcup - (int)(wi * 4), 0), 4);           /* stream bytes in this lane's dword */
+        uint32_t dw = nv > 0 ? Dw[wi] : 0u;
+        if (nv < 4) dw &= nv ? (0xFFFFFFFFu >> (32 - 8 * nv)) : 0u;
+        const uint32_t b0 = dw & 0xFF, b1 = (dw >> 8) & 0xFF, b2 = (dw >> 16) & 0xFF, b3 = dw >> 24;
+        uint32_t prev = ht_dpp_left(b3);
+        if (lane == 0) prev = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)b3, 63);
+        const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n1 = nv > 1 ? (b0 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n2 = nv > 2 ? (b1 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n3 = nv > 3 ? (b2 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+        const uint32_t chunk = b0 | (b1 << o1) | (b2 << o2) | (b3 << o3);   /* o3 <= 24: fits */
+        const uint32_t incl = wave_incl_scan_u32(tot, lane);
+        const uint32_t off = base + incl - tot, sh = off & 31;
+        if (nv > 0) {
+            atomicOr(&ms[off >> 5], chunk << sh);
+            if (sh) atomicOr(&ms[(off >> 5) + 1], chunk >> (32 - sh));
+        }
+        base += wave_last(incl);
+    }
+    return base;
+}
+
 template <int TRANSFORM, bool REFINE>
 __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
                                                      uint32_t *__restrict__ dst, uint32_t *bm, int lane, int w, int h,
@@ -308,8 +344,7 @@ template <bool EXTERNAL_VLC>
 __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
-            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
-            const uint32_t *__restrict__ ms_u)
+            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -369,37 +404,15 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
         for (uint32_t i = lane; i < nvl; i += 64) vlcw[i] = 0;
     }
-    for (uint32_t i = lane; i < nms; i += 64) ms[i] = 0;
+    for (uint32_t i = lane; i <= nms; i += 64) ms[i] = 0;
     for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
     for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
     if (z_blk > 1)
         for (uint32_t i = lane; i < 4 * L.bm_words; i += 64) bm[i] = 0;
     __syncthreads();
 
-    uint32_t ms_total = 0;
-    if (EXTERNAL_VLC) {
-        /* un-stuffed (and ones-padded) by k_ht_unstuff: a plain coalesced copy */
-        const uint32_t *src = ms_u + (b.data_off >> 2);
-        for (uint32_t i = lane; i < nms; i += 64) ms[i] = src[i];
-        if (lane == 0) ms[nms] = 0xFFFFFFFFu;
-    } else {   /* MagSgn: forward, a byte after 0xFF advances 7 bits but ORs all 8 (jpeg2000htdec.c:207-221) */
-        uint32_t base = 0;
-        for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const bool act = i < Pcup;
-            const uint32_t byte = act ? D[i] : 0;
-            const uint32_t prev = (act && i > 0) ? D[i - 1] : 0;
-            const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
-            const uint32_t incl = wave_incl_scan_u32(nb, lane);
-            const uint32_t off = base + incl - nb;
-            if (act) {
-                atomicOr(&ms[off >> 5], byte << (off & 31));
-                if ((off & 31) > 24) atomicOr(&ms[(off >> 5) + 1], byte >> (32 - (off & 31)));
-            }
-            base += wave_last(incl);
-        }
-        ms_total = base;
-    }
+    /* MagSgn: un-stuffed here in both modes, straight into LDS */
+    const uint32_t ms_total = ht_unstuff_magsgn(D, Pcup, ms, lane);
     if (!EXTERNAL_VLC) {   /* VLC: backward from Dcup[Lcup-2]; Dcup[Lcup-1] counts as 0xFF and the low nibble of
          * Dcup[Lcup-2] as 0xF (:1277-1278); a byte with 7 LSBs set below a byte > 0x8F loses its MSB */
         uint32_t base = 0;
@@ -432,7 +445,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         suf[i] = (uint8_t)v;
     }
     __syncthreads();
-    for (uint32_t i = lane; !EXTERNAL_VLC && i < nms; i += 64) {        /* past the end the MagSgn stream is all ones */
+    for (uint32_t i = lane; i <= nms; i += 64) {                        /* past the end the MagSgn stream is all ones */
         if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
         else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
     }
@@ -717,12 +730,12 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
 
 
 /* ================================================================== split pipeline
- * k_ht_unstuff  (wave per block)  removes the bit stuffing of all three byte streams of the
- *               cleanup segment in parallel (per-byte bit counts, wave prefix sum, ds_or) and
- *               writes them as plain bit arrays: MagSgn LSB-first padded with ones
- *               (jpeg2000htdec.c:207-221), VLC LSB-first in read order padded with zeros
- *               (:145-201, first 4 bits = the Scup nibble), MEL MSB-first padded with ones
- *               (:429-440).
+ * k_ht_unstuff  (wave per block)  removes the bit stuffing of the VLC and MEL byte streams of the
+ *               cleanup segment in parallel (four bytes per lane: per-byte bit counts, wave
+ *               prefix sum, ds_or) and writes them as plain bit arrays: VLC LSB-first in read
+ *               order padded with zeros (jpeg2000htdec.c:145-201, first 4 bits = the Scup
+ *               nibble), MEL MSB-first padded with ones (:429-440).  (MagSgn is un-stuffed by
+ *               k_ht_decode itself, straight into LDS.)
  * k_ht_vlc      (LANE per block)  the serial MEL / CxtVLC / U-VLC chain (:632-973); 64 blocks
  *               per wavefront.  With stuffing gone a refill is "append the next dword", a MEL
  *               read is a shift, and the first-row / other-row / paired / unpaired U-VLC cases
@@ -733,8 +746,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
  * trip counts. */
 __global__ void __launch_bounds__(64)
 k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
-             uint32_t *__restrict__ ms_u, uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u,
-             uint32_t lds_words)
+             uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u, uint32_t lds_words)
 {
     extern __shared__ __align__(16) uint32_t sw[];
     const int lane = threadIdx.x;
@@ -746,100 +758,101 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     const uint32_t Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
     if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
     const uint32_t Pcup = Lcup - Scup;
-    const uint32_t nms = (Pcup * 8 + 31) / 32 + 2, nsw = (Scup * 8 + 31) / 32 + 2;
-    if (nms > lds_words || nsw > lds_words) return;      /* host sized the LDS from the same fields */
-    uint32_t *msO = ms_u + (b.data_off >> 2), *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
+    const uint32_t nsw = (Scup * 8 + 31) / 32 + 2;
+    if (2 * nsw > lds_words) return;                     /* host sized the LDS from the same fields */
+    uint32_t *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
+    uint32_t *sv = sw, *sm = sw + nsw;
 
-    /* ---- MagSgn ---- */
-    for (uint32_t i = lane; i < nms; i += 64) sw[i] = 0;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t i0 = 0; i0 < Pcup; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const bool act = i < Pcup;
-        const uint32_t byte = act ? D[i] : 0;
-        const uint32_t prev = (act && i > 0) ? D[i - 1] : 0;
-        const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t incl = wave_incl_scan_u32(nb, lane);
-        const uint32_t off = base + incl - nb;
-        if (act) {
-            atomicOr(&sw[off >> 5], byte << (off & 31));
-            if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], byte >> (32 - (off & 31)));
-        }
-        base += wave_last(incl);
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < nms; i += 64) {
-        uint32_t v = sw[i];
-        if (i * 32 >= base) v = 0xFFFFFFFFu;
-        else if (i * 32 + 32 > base) v |= 0xFFFFFFFFu << (base & 31);
-        msO[i] = v;
-    }
+    for (uint32_t i = lane; i < 2 * nsw; i += 64) sw[i] = 0;
     __syncthreads();
 
-    /* ---- VLC (backward) ---- */
-    for (uint32_t i = lane; i < nsw; i += 64) sw[i] = 0;
-    __syncthreads();
-    base = 0;
-    const uint32_t nv = Scup - 1;
-    for (uint32_t k0 = 0; k0 < nv; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        const bool act = k < nv;
-        uint32_t v = 0, above = 0xFF;
-        if (act) {
-            const uint32_t j = Lcup - 2 - k;
-            v = D[j];
-            if (k == 0) v |= 0x0F;
-            else { above = D[j + 1]; if (k == 1) above |= 0x0F; }
-        }
-        const uint32_t nb = act ? ((above > 0x8F && (v & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-        v &= (1u << nb) - 1;
-        const uint32_t incl = wave_incl_scan_u32(nb, lane);
-        const uint32_t off = base + incl - nb;
-        if (act) {
-            atomicOr(&sw[off >> 5], v << (off & 31));
-            if ((off & 31) > 24) atomicOr(&sw[(off >> 5) + 1], v >> (32 - (off & 31)));
-        }
-        base += wave_last(incl);
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < nsw; i += 64) vlO[i] = sw[i];
-    __syncthreads();
-
-    /* ---- MEL (forward from Dcup[Pcup], MSB-first) ---- */
-    for (uint32_t i = lane; i < nsw; i += 64) sw[i] = 0;
-    __syncthreads();
-    base = 0;
-    for (uint32_t i0 = 0; i0 < Scup; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const bool act = i < Scup;
-        uint32_t v = 0, prev = 0;
-        if (act) {
-            const uint32_t a = Pcup + i;
-            v = D[a];
-            if (a == Lcup - 1) v = 0xFF; else if (a == Lcup - 2) v |= 0x0F;       /* modDcup, :1277-1278 */
-            if (i > 0) { prev = D[a - 1]; if (a - 1 == Lcup - 2) prev |= 0x0F; }
-        }
-        const uint32_t nb = act ? (prev == 0xFF ? 7u : 8u) : 0u;
-        v &= (1u << nb) - 1;
-        const uint32_t incl = wave_incl_scan_u32(nb, lane);
-        const uint32_t off = base + incl - nb;             /* stream position of the byte's first (top) bit */
-        if (act) {
-            const uint32_t sh = off & 31;                  /* place v's nb bits at [31-sh .. 31-sh-nb+1] */
-            if (sh + nb <= 32) atomicOr(&sw[off >> 5], v << (32 - sh - nb));
-            else {
-                const uint32_t spill = sh + nb - 32;
-                atomicOr(&sw[off >> 5], v >> spill);
-                atomicOr(&sw[(off >> 5) + 1], v << (32 - spill));
+    /* ---- VLC: backward from Dcup[Lcup-2]; four bytes per lane and pass, in read order
+     * r0 = Dcup[j] .. r3 = Dcup[j-3].  Dcup[Lcup-2] counts with its low nibble set (:1277-1278);
+     * a byte whose 7 LSBs are set loses its MSB when the byte read before it is > 0x8F
+     * (:145-201), the byte "before" the first one being 0xFF. ---- */
+    {
+        uint32_t base = 0, carry = 0xFF;
+        const uint32_t nvb = Scup - 1;                   /* bytes Lcup-2 .. Pcup */
+        for (uint32_t k0 = 0; k0 < nvb; k0 += 256) {
+            const uint32_t k = k0 + 4 * lane;            /* read index of r0 */
+            const int nv = min(max((int)nvb - (int)k, 0), 4);
+            uint32_t dw = 0;
+            if (nv > 0) {                                /* Dcup[j-3 .. j], j = Lcup-2-k; the 16 bytes in front of the
+                                                          * first block of the buffer are padding (j2k_parse.c) */
+                const uint8_t *p = D + (Lcup - 2 - k) - 3;
+                __builtin_memcpy(&dw, p, 4);
             }
+            uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
+            if (k == 0) r0 |= 0x0F;
+            if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
+            uint32_t above = ht_dpp_left(r3);
+            if (lane == 0) above = carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
+            const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+            const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
+                                   ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
+            const uint32_t incl = wave_incl_scan_u32(tot, lane);
+            const uint32_t off = base + incl - tot, sh = off & 31;
+            if (nv > 0) {
+                atomicOr(&sv[off >> 5], chunk << sh);
+                if (sh) atomicOr(&sv[(off >> 5) + 1], chunk >> (32 - sh));
+            }
+            base += wave_last(incl);
         }
-        base += wave_last(incl);
+    }
+
+    /* ---- MEL: forward from Dcup[Pcup], MSB-first; Dcup[Lcup-1] counts as 0xFF, Dcup[Lcup-2] with
+     * its low nibble set; a byte after 0xFF has 7 bits (:429-440) ---- */
+    uint32_t mel_bits = 0;
+    {
+        uint32_t base = 0, carry = 0;
+        for (uint32_t i0 = 0; i0 < Scup; i0 += 256) {
+            const uint32_t i = i0 + 4 * lane;
+            const int nv = min(max((int)Scup - (int)i, 0), 4);
+            uint32_t dw = 0;
+            if (nv > 0) __builtin_memcpy(&dw, D + Pcup + i, 4);      /* the block's 8 trailing pad bytes cover the tail */
+            uint32_t m[4] = { dw & 0xFF, (dw >> 8) & 0xFF, (dw >> 16) & 0xFF, dw >> 24 };
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t a = Pcup + i + q;
+                if (a == Lcup - 1) m[q] = 0xFF;
+                else if (a == Lcup - 2) m[q] |= 0x0F;
+                if (q >= nv) m[q] = 0;
+            }
+            uint32_t prev = ht_dpp_left(m[3]);
+            if (lane == 0) prev = carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)m[3], 63);
+            const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
+            const uint32_t n1 = nv > 1 ? (m[0] == 0xFF ? 7u : 8u) : 0u;
+            const uint32_t n2 = nv > 2 ? (m[1] == 0xFF ? 7u : 8u) : 0u;
+            const uint32_t n3 = nv > 3 ? (m[2] == 0xFF ? 7u : 8u) : 0u;
+            const uint32_t tot = n0 + n1 + n2 + n3;
+            /* first byte in the most significant bits */
+            uint32_t chunk = m[0] & ((1u << n0) - 1);
+            chunk = (chunk << n1) | (m[1] & ((1u << n1) - 1));
+            chunk = (chunk << n2) | (m[2] & ((1u << n2) - 1));
+            chunk = (chunk << n3) | (m[3] & ((1u << n3) - 1));
+            const uint32_t incl = wave_incl_scan_u32(tot, lane);
+            const uint32_t off = base + incl - tot, sh = off & 31;
+            if (nv > 0) {
+                const uint32_t left = chunk << (32 - tot);            /* tot is 7..32 here */
+                atomicOr(&sm[off >> 5], left >> sh);
+                if (sh) atomicOr(&sm[(off >> 5) + 1], left << (32 - sh));
+            }
+            base += wave_last(incl);
+        }
+        mel_bits = base;
     }
     __syncthreads();
-    for (uint32_t i = lane; i < nsw; i += 64) {            /* 0xFF bytes forever past the segment */
-        uint32_t v = sw[i];
-        if (i * 32 >= base) v = 0xFFFFFFFFu;
-        else if (i * 32 + 32 > base) v |= 0xFFFFFFFFu >> (base & 31);
+    for (uint32_t i = lane; i < nsw; i += 64) {
+        vlO[i] = sv[i];
+        uint32_t v = sm[i];                               /* 0xFF bytes forever past the segment */
+        if (i * 32 >= mel_bits) v = 0xFFFFFFFFu;
+        else if (i * 32 + 32 > mel_bits) v |= 0xFFFFFFFFu >> (mel_bits & 31);
         meO[i] = v;
     }
 }

@@ -97,7 +97,7 @@ struct htj2k_job {
     std::vector<hipEvent_t> lev_ev;    /* per-IDWT-launch brackets (roofline measurement) */
     int lev_ev_used = 0;
     std::vector<double> lev_bytes, lev_hbm;   /* algorithmic / least-HBM bytes of each recorded launch */
-    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_msu, d_vlcu, d_melu;
+    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_vlcu, d_melu;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     size_t nquads = 0;
     HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
@@ -234,7 +234,7 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     if (j->stream) (void)hipStreamSynchronize(j->stream);
     j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
     j->d_t0.release(); j->d_t1.release(); j->d_desc.release(); j->d_qsym.release(); j->d_qoff.release();
-    j->d_msu.release(); j->d_vlcu.release(); j->d_melu.release();
+    j->d_vlcu.release(); j->d_melu.release();
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
@@ -315,6 +315,8 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
         F.block_base = (uint32_t)j->blocks.size();
         F.tc_base = (uint32_t)j->tilecomps.size();
         F.sample_base = (uint32_t)nsamples;
+        nbytes += 16;                                  /* k_ht_unstuff's backward dword loads may start up to 3 bytes
+                                                        * in front of a block: never in front of the buffer */
         F.bytes_base = nbytes;
         for (int i = 0; i < pl->nblocks; i++) {
             J2kBlock b = pl->blocks[i];
@@ -707,8 +709,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_qsym.ensure((j->nquads + 64) * sizeof(uint32_t))) < 0) return r;
     if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
-    if ((r = j->d_msu.ensure(j->nbytes + 256)) < 0 || (r = j->d_vlcu.ensure(j->nbytes + 256)) < 0 ||
-        (r = j->d_melu.ensure(j->nbytes + 256)) < 0) return r;
+    if ((r = j->d_vlcu.ensure(j->nbytes + 256)) < 0 || (r = j->d_melu.ensure(j->nbytes + 256)) < 0) return r;
     for (int f = 0; f < j->nframes; f++) {
         FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
@@ -880,13 +881,13 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
-                const uint32_t us_words = j->lds.ms_words > j->lds.vlc_words ? j->lds.ms_words : j->lds.vlc_words;
+                const uint32_t us_words = 2 * j->lds.vlc_words;
                 const uint32_t us_lds = us_words * 4;
                 if (us_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
                 hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                   (uint32_t *)j->d_msu.p, (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                                   (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
                 hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
@@ -894,14 +895,14 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
-                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, (const uint32_t *)j->d_msu.p);
+                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p);
             } else {
                 if ((int)j->lds.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
                 hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             }
             HIP_TRY(c, hipGetLastError());
         }
@@ -1293,11 +1294,27 @@ extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int 
 
 /* HT block decoder alone: decode `n` codeblocks given as a descriptor table + byte pool into
  * a sample buffer (unit parity against ff_jpeg2000_decode_htj2k + dequantisation) */
-extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, const uint8_t *bytes, size_t nbytes,
+extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks, const uint8_t *bytes_in, size_t nbytes_in,
                                void *coef, size_t nsamples, int *status)
 {
-    if (!c || !blocks || nblocks <= 0 || !bytes || !coef) return HTJ2K_ERR_EINVAL;
+    if (!c || !blocks_in || nblocks <= 0 || !bytes_in || !coef) return HTJ2K_ERR_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
+    /* the kernels want the layout j2k_parse.c produces: every block's bytes at a 16-byte aligned
+     * offset, 8+ pad bytes behind them and 16 in front of the first: re-pack the caller's pool */
+    std::vector<J2kBlock> blk((const J2kBlock *)blocks_in, (const J2kBlock *)blocks_in + nblocks);
+    std::vector<uint8_t> pool(16, 0);
+    for (int i = 0; i < nblocks; i++) {
+        J2kBlock &b = blk[i];
+        const size_t len = (size_t)b.lcup + b.lref;
+        if ((size_t)b.data_off + len > nbytes_in) return HTJ2K_ERR_EINVAL;
+        const size_t o = pool.size();
+        pool.resize(o + ((len + 8 + 15) & ~(size_t)15), 0);
+        memcpy(pool.data() + o, bytes_in + b.data_off, len);
+        b.data_off = (uint32_t)o;
+    }
+    const void *blocks = blk.data();
+    const uint8_t *bytes = pool.data();
+    const size_t nbytes = pool.size();
     struct { HtLds lds, ext; } tmp;
     const uint8_t *bases[1] = { bytes };
     int r = build_ht_lds(c, (const J2kBlock *)blocks, nblocks, bases, nullptr, &tmp.lds, &tmp.ext);
@@ -1309,16 +1326,15 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
         qoff[i] = (uint32_t)nq;
         if (b.npasses) nq += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
     }
-    DevBuf db, dby, dc, ds, dq, dqo, du[3];
+    DevBuf db, dby, dc, ds, dq, dqo, du[2];
     if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
-        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 ||
-        (r = du[2].ensure(nbytes + 256)) < 0) {
-        dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
+        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0) {
+        dq.release(); dqo.release(); du[0].release(); du[1].release();
         return r;
     }
     if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
         (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0) {
-        db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
+        db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release();
         return r;
     }
     hipError_t e = hipMemcpy(db.p, blocks, (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice);
@@ -1333,18 +1349,18 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
         if (e == hipSuccess && (int)tmp.ext.total > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
-            const uint32_t us_words = tmp.lds.ms_words > tmp.lds.vlc_words ? tmp.lds.ms_words : tmp.lds.vlc_words;
+            const uint32_t us_words = 2 * tmp.lds.vlc_words;
             const uint32_t us_lds = us_words * 4;
             if (us_lds > 48 * 1024)
                 (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
             hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
-                               (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, (uint32_t *)du[2].p, us_words);
+                               (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
             hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
-                               tmp.lds.max_qw, (const uint32_t *)du[1].p, (const uint32_t *)du[2].p, 0);
+                               tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, 0);
             hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), tmp.ext.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.ext,
-                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p);
+                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p);
             e = hipDeviceSynchronize();
         }
     } else if (e == hipSuccess) {
@@ -1353,14 +1369,14 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks, int nblocks, co
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             e = hipDeviceSynchronize();
         }
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
-    db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release(); du[2].release();
+    db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release();
     if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_ht_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
     return 0;
 }
