@@ -242,96 +242,103 @@ template <int TRANSFORM, bool REFINE>
 __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
                                                      uint32_t *__restrict__ dst, uint32_t *bm, int lane, int w, int h,
                                                      int stride, int pLSB, int maxbp, int M_b, float fscale, int i_step,
-                                                     uint32_t last_wi)
+                                                     uint32_t last_wi, uint32_t *__restrict__ sink)
 {
-    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1, ncols = 2 * qw;
+    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
     const int col = lane;
-    const bool act = col < ncols;
+    const bool act = col < 2 * qw;                         /* lanes past the block read qi = 0: no bits, exponent 0 */
+    const bool st_ok = col < w;
     const int q = col >> 1, sh = (col & 1) * 2;
     const int bmW = w + 2;
     const int dshift = 31 - M_b;
+    const uint32_t half = 1u << ((pLSB - 1) & 31);
     uint32_t ms_pos = 0, Eb = 0;
     int err = 0;
-    uint32_t qi_next = act ? qglob[q] : 0u;
+    const uint32_t *qp = qglob + q;
+    uint32_t qi_next = act ? *qp : 0u;
+    uint32_t *prow = dst + col;                            /* this lane's column, row 2 * row */
     for (int row = 0; row < qh; row++) {
         const uint32_t qi = qi_next;
-        if (row + 1 < qh) qi_next = act ? qglob[(row + 1) * qw + q] : 0u;
-        const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+        qp += qw;
+        if (row + 1 < qh) qi_next = act ? *qp : 0u;
+        const uint32_t rho = qi & 0xF, uq = (qi >> 16) & 0xFF;
+        /* this lane's samples: top = bit sh, bottom = bit sh + 1 of rho / e_k / e_1 */
+        const uint32_t s_t = (qi >> sh) & 1, s_b = (qi >> (sh + 1)) & 1;
+        const uint32_t k_t = (qi >> (sh + 4)) & 1, k_b = (qi >> (sh + 5)) & 1;
+        const uint32_t e_t = (qi >> (sh + 8)) & 1, e_b = (qi >> (sh + 9)) & 1;
         int kappa = 1;
         if (row > 0) {
-            /* quad q spans columns 2q, 2q+1; it looks at the bottom exponents of columns 2q-1 .. 2q+2 */
             /* own-lane neighbours cover columns c-1, c+1; together with the pair partner's
              * (c^1)-1, (c^1)+1 that is exactly 2q-1 .. 2q+2 -- no lane-dependent select, so no
              * DPP ends up under a divergent EXEC mask */
             const uint32_t nbm = max(ht_dpp_left(Eb), ht_dpp_right(Eb));
             const uint32_t pm = max(Eb, ht_dpp_swap_pair(Eb));
             const int me = (int)max(pm, max(nbm, ht_dpp_swap_pair(nbm)));
-            const int gamma = (rho & (rho - 1)) != 0;
-            kappa = max(1, gamma * (me - 1));
+            kappa = (rho & (rho - 1)) ? max(me - 1, 1) : 1;           /* gamma: more than one significant sample */
         }
-        const int U = kappa + uq;
+        const int U = kappa + (int)uq;
         if (act && U > maxbp) err = 1;
-        const int s_t = (rho >> sh) & 1, s_b = (rho >> (sh + 1)) & 1;
-        const int m_t = act ? s_t * U - ((ekq >> sh) & 1) : 0;
-        const int m_b = act ? s_b * U - ((ekq >> (sh + 1)) & 1) : 0;
+        const int m_t = (s_t ? U : 0) - (int)k_t, m_b = (s_b ? U : 0) - (int)k_b;
         const uint32_t nt = (uint32_t)max(m_t, 0), nb = (uint32_t)max(m_b, 0);
         const uint32_t incl = wave_incl_scan_u32(nt + nb, lane);
         const uint32_t pos = ms_pos + incl - nt - nb;
         ms_pos += wave_last(incl);
-        /* 96-bit window: both samples (<= 62 bits) start at bit pos & 31 */
-        /* words last_wi .. last_wi + 2 are the all-ones continuation of the stream (:207-221) */
+        /* 96-bit window; words last_wi .. last_wi + 2 are the all-ones continuation of the stream (:207-221) */
         const uint32_t wi = min(pos >> 5, last_wi), bs = pos & 31;
         const uint32_t w0 = ms[wi], w1 = ms[wi + 1], w2 = ms[wi + 2];
-        const uint64_t lo64 = ((uint64_t)w1 << 32) | w0;
-        const uint64_t win = bs ? ((lo64 >> bs) | ((uint64_t)w2 << (64 - bs))) : lo64;
-        uint32_t vt = (uint32_t)(win & ((1ull << nt) - 1));
-        uint32_t vb = (uint32_t)((win >> nt) & ((1ull << nb) - 1));
-        if (m_t > 0) vt += (uint32_t)((e1q >> sh) & 1) << m_t;
-        if (m_b > 0) vb += (uint32_t)((e1q >> (sh + 1)) & 1) << m_b;
-        uint32_t mu_t = 0, mu_b = 0;
-        Eb = 0;
-        if (m_t != 0) mu_t = ((((vt >> 1) + 1) << pLSB) | (1u << ((pLSB - 1) & 31))) | ((vt & 1) << 31);
-        if (m_b != 0) {
-            mu_b = ((((vb >> 1) + 1) << pLSB) | (1u << ((pLSB - 1) & 31))) | ((vb & 1) << 31);
-            Eb = (uint32_t)(32 - __clz((int)(vb | 1)));
-        }
-        if (!act) Eb = 0;
-        const int y0 = 2 * row;
-        if (act && col < w) {
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int y = y0 + r;
-                if (y >= h) continue;
-                const uint32_t smag = r ? mu_b : mu_t;
-                if (REFINE) {
-                    dst[(size_t)y * stride + col] = smag;
-                    if ((rho >> (sh + r)) & 1)
-                        atomicOr(&bm[((y + 1) * bmW + col + 1) >> 5], 1u << (((y + 1) * bmW + col + 1) & 31));
-                } else {
-                    const uint32_t mag = smag & 0x7FFFFFFFu;
-                    const bool neg = (smag >> 31) != 0;
-                    uint32_t outv;
-                    if (TRANSFORM == J2K_DWT53) {
-                        int v = (int)(mag >> dshift);
-                        if (neg) v = -v;
-                        if (i_step != 32768) {
-                            long long t = (long long)v * i_step;
-                            v = (int)(t < 0 ? -((-t) >> 16) : (t >> 16));
-                        }
-                        outv = (uint32_t)v;
-                    } else if (TRANSFORM == J2K_DWT97) {
-                        const int v = neg ? -(int)mag : (int)mag;
-                        outv = __float_as_uint((float)v * fscale);
-                    } else {
-                        int v = neg ? -(int)mag : (int)mag;
-                        v = (v + 32) >> 6;
-                        const long long t = (long long)v * i_step;
-                        outv = (uint32_t)(int)((t + (1 << 15)) >> 16);
-                    }
-                    dst[(size_t)y * stride + col] = outv;
+        /* v_alignbit takes the shift mod 32, v_bfe a width of 0..31 */
+        uint32_t vt = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, bs), 0u, nt);
+        const uint32_t sb = bs + nt;                       /* 0 .. 62 */
+        const bool hiw = sb >= 32;
+        uint32_t vb = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hiw ? w2 : w1, hiw ? w1 : w0, sb), 0u, nb);
+        /* a negative m (e_k outside rho: not in the Annex C tables) reads no bits and has v = 0 */
+        vt = m_t > 0 ? vt + (e_t << nt) : 0u;
+        vb = m_b > 0 ? vb + (e_b << nb) : 0u;
+        uint32_t mu_t = ((((vt >> 1) + 1) << pLSB) | half) | (vt << 31);
+        uint32_t mu_b = ((((vb >> 1) + 1) << pLSB) | half) | (vb << 31);
+        mu_t = m_t != 0 ? mu_t : 0u;
+        mu_b = m_b != 0 ? mu_b : 0u;
+        Eb = m_b != 0 ? (uint32_t)(32 - __clz((int)(vb | 1))) : 0u;
+        const bool two = 2 * row + 1 < h;                  /* odd heights: the outside half of the last quad row is discarded (:976-1007) */
+        if (REFINE) {
+            if (st_ok) {
+                const int y0 = 2 * row;
+                prow[0] = mu_t;
+                if (s_t) atomicOr(&bm[((y0 + 1) * bmW + col + 1) >> 5], 1u << (((y0 + 1) * bmW + col + 1) & 31));
+                if (two) {
+                    prow[stride] = mu_b;
+                    if (s_b) atomicOr(&bm[((y0 + 2) * bmW + col + 1) >> 5], 1u << (((y0 + 2) * bmW + col + 1) & 31));
                 }
             }
+        } else {
+            uint32_t o_t, o_b;
+            if (TRANSFORM == J2K_DWT53) {
+                const int sg_t = (int)mu_t >> 31, sg_b = (int)mu_b >> 31;
+                int r_t = (int)((mu_t & 0x7FFFFFFFu) >> dshift), r_b = (int)((mu_b & 0x7FFFFFFFu) >> dshift);
+                r_t = (r_t ^ sg_t) - sg_t;
+                r_b = (r_b ^ sg_b) - sg_b;
+                if (i_step != 32768) {                      /* wave-uniform; reversible bands have step 1.0 */
+                    const long long a = (long long)r_t * i_step, b2 = (long long)r_b * i_step;
+                    r_t = (int)(a < 0 ? -((-a) >> 16) : (a >> 16));
+                    r_b = (int)(b2 < 0 ? -((-b2) >> 16) : (b2 >> 16));
+                }
+                o_t = (uint32_t)r_t; o_b = (uint32_t)r_b;
+            } else if (TRANSFORM == J2K_DWT97) {
+                /* (float)(-x) * s == -((float)x * s), and a zero magnitude never carries a sign */
+                o_t = __float_as_uint((float)(mu_t & 0x7FFFFFFFu) * fscale) | (mu_t & 0x80000000u);
+                o_b = __float_as_uint((float)(mu_b & 0x7FFFFFFFu) * fscale) | (mu_b & 0x80000000u);
+            } else {
+                o_t = ht_dequant(mu_t, TRANSFORM, M_b, 0, fscale, i_step);
+                o_b = ht_dequant(mu_b, TRANSFORM, M_b, 0, fscale, i_step);
+            }
+            /* exactly two stores per row, no branch around them: lanes (and the odd last row) that
+             * have nothing to write aim at a scratch dword.  With a fixed number of stores behind
+             * the prefetch of the next row's symbols the wait at the loop top is vmcnt(2), not
+             * vmcnt(0) -- the rows of a block no longer wait for each other's stores to land. */
+            *(st_ok ? prow : sink) = o_t;
+            *((st_ok && two) ? prow + stride : sink) = o_b;
         }
+        prow += 2 * stride;
     }
     return __any(err) ? HT_ERR_INVALID : 0;
 }
@@ -344,7 +351,8 @@ template <bool EXTERNAL_VLC>
 __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
-            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff)
+            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
+            uint32_t *__restrict__ sink)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -404,9 +412,12 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
         for (uint32_t i = lane; i < nvl; i += 64) vlcw[i] = 0;
     }
+    const bool fast = EXTERNAL_VLC && 2 * qw <= 64 && b.roi_shift == 0;   /* ht_magsgn_rows_narrow: no LDS exponent rows */
     for (uint32_t i = lane; i <= nms; i += 64) ms[i] = 0;
-    for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
-    for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
+    if (!fast) {
+        for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
+        for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
+    }
     if (z_blk > 1)
         for (uint32_t i = lane; i < 4 * L.bm_words; i += 64) bm[i] = 0;
     __syncthreads();
@@ -466,16 +477,15 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     int ctx_run = 0;                                   /* first-row context carried along the row */
     const int bmW = w + 2;                             /* bitmap row pitch (1-cell border) */
 
-    const bool fast = EXTERNAL_VLC && 2 * qw <= 64 && roi_shift == 0;
     if (fast) {
         if (z_blk > 1) {
-            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
-            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
-            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
         } else {
-            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
-            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
-            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2);
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
         }
     }
     for (int row = 0; row < qh && !err && !fast; row++) {

@@ -891,18 +891,19 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
-                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, getenv("HTJ2K_DBG") ? atoi(getenv("HTJ2K_DBG")) : 0);
+                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, 0);
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
-                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p);
+                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                   (uint32_t *)j->d_coef.p + j->nsamples + 32);
             } else {
                 if ((int)j->lds.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
                 hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)j->d_coef.p + j->nsamples + 32);
             }
             HIP_TRY(c, hipGetLastError());
         }
@@ -1360,7 +1361,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, 0);
             hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), tmp.ext.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.ext,
-                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p);
+                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (uint32_t *)dc.p + nsamples + 8);
             e = hipDeviceSynchronize();
         }
     } else if (e == hipSuccess) {
@@ -1369,7 +1370,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)dc.p + nsamples + 8);
             e = hipDeviceSynchronize();
         }
     }
