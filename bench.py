@@ -45,6 +45,24 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 COPY_CEILING_GBS = 6290.0      # same guide, line 36: float4 copy, 79 % of the spec
 
 
+def committed_traffic(frames_per_step):
+    """HBM bytes per IDWT launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+    process): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the IDWT launches of one step of this same
+    workload (tools/prof_r01.sh + tools/make_profiles.py); None when the batch differs from the profiled one."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for name in sorted(os.listdir(pdir)):
+            if name.endswith("_idwt_traffic.json"):
+                try:
+                    d = json.load(open(os.path.join(pdir, name)))
+                    if d.get("frames_per_step") == frames_per_step:
+                        best = (d["hbm_bytes_per_launch"], name)
+                except (OSError, ValueError, KeyError):
+                    pass
+    return best
+
+
 def shard_frames(nframes, rank, world):
     """frame i -> rank i mod world"""
     return list(range(rank, nframes, world))
@@ -180,6 +198,7 @@ def main():
     if rank == 0:
         achieved = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
         achieved_hbm = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
+        traffic = committed_traffic(args.batch) if njobs == 1 else None
         res = {
             "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3)",
             "value": round(value, 2),
@@ -202,7 +221,9 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "k_idwt_stream<5/3> (levels 1-4) + k_idwt_stream_pack<5/3,3> (level 5 fused with RCT + rgb24 store)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
                          "launches": nlaunch, "avg_launch_us": round(idwt_launch_ms / max(nlaunch, 1) * 1e3, 2),
                          "algorithmic_MB_per_launch": round(idwt_launch_bytes / max(nlaunch, 1) / 1e6, 3),
                          "achieved_min_hbm_traffic": round(achieved_hbm, 1),
