@@ -192,8 +192,13 @@ int  htj2k_job_block_errors(htj2k_ctx *ctx, htj2k_job *job);
 int  htj2k_job_num_blocks(const htj2k_job *job);
 /* device address of an output plane, for callers that keep decoded frames on the GPU */
 void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
-/* tuning / test knobs: "idwt_mode" (0 generic kernels, 1 fused LDS tile kernels),
- * "bitexact", "reduction_factor" */
+/* tuning / test knobs:
+ *   "idwt_mode"   0 generic closed-form kernels, 1 LDS tile kernel, 2 LDS + DPP tile kernel,
+ *                 3 register-streaming kernel (default)
+ *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
+ *                 lets the final IDWT level do the inverse MCT and write the frame
+ *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
+ *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
 
 const char *htj2k_version(void);
