@@ -101,6 +101,40 @@ def test_stage_planes_match_oracle(dec, orc, name):
         dec.set_int("idwt_mode", 3)
 
 
+@pytest.mark.parametrize("fuse", [1, 0], ids=["fused", "unfused"])
+def test_batch_job_of_mixed_frames(dec, orc, fuse):
+    """one job = a batch of frames of different formats: every stage is one launch over merged
+    descriptor tables; fusable tiles (rgb24, gray, 4:4:4 planar) and unfusable ones (4:2:0, 4:2:2
+    12-bit 9/7, 16-bit, tiles with odd origins) share the launches of a level"""
+    names = ["rgb_mct", "gray_l5_cb64", "yuv420p8", "rgb_97_ict", "yuv422p12_97", "gray16", "rgb_tiles_offsets",
+             "rgb10_mct", "rgba8", "gray_3passes", "tiny_3x1_l2", "rgb_mct"]
+    names = [n for n in names if not streams.get(n)[1]]           # default decoder options only
+    pkts = [streams.get(n)[0] for n in names]
+    dec.set_int("idwt_mode", 3)
+    dec.set_int("fuse_pack", fuse)
+    try:
+        job = dec.job().parse_batch(pkts).upload().run().wait()
+        assert job.block_errors() == 0
+        launches = job.idwt_launches()
+        hbm = job.idwt_hbm_bytes()
+        assert len(launches) == len(hbm) > 0
+        for (ms, by), hb in zip(launches, hbm):
+            assert ms >= 0 and 0 < hb <= by                     # a fused final level moves less than 2*4*lh*lv
+        if fuse:
+            assert any(hb < by for (ms, by), hb in zip(launches, hbm))
+        else:
+            assert all(hb == by for (ms, by), hb in zip(launches, hbm))
+        for f, name in enumerate(names):
+            info_o, planes_o, _ = orc.decode(pkts[f])
+            info, planes = job.download_frame(f)
+            assert (info.width, info.height, info.pix_fmt) == (info_o.width, info_o.height, info_o.pix_fmt), name
+            for a, b in zip(planes, planes_o):
+                assert np.array_equal(a, b), name
+        job.free()
+    finally:
+        dec.set_int("fuse_pack", 1)
+
+
 def test_idwt_random_borders(dec):
     """the reference's own DWT unit test shape (libavcodec/tests/jpeg2000dwt.c): random
     borders incl. odd origins, 1..3 sample lines, levels deeper than the size allows"""
