@@ -125,10 +125,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    # rehearsal knobs (never set by the driver): several ranks on the one GPU of a test box, over gloo
+    backend = os.environ.get("HTJ2K_BENCH_BACKEND", "nccl")
+    device = int(os.environ["HTJ2K_BENCH_DEVICE"]) if "HTJ2K_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend)
     import ffmpeg_ht_amd as m
 
     streams = make_streams(min(args.distinct, args.batch), rank)
@@ -136,7 +139,7 @@ def main():
     njobs = max(1, min(args.jobs, args.batch))
     per_job = [batch[i::njobs] for i in range(njobs)]
 
-    dec = m.Decoder(device_id=local_rank if world > 1 else 0)
+    dec = m.Decoder(device_id=device)
     t0 = time.perf_counter()
     jobs = [dec.job().parse_batch(b) for b in per_job]
     t_parse = time.perf_counter() - t0
