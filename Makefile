@@ -23,7 +23,10 @@ $(CSRC)/j2k_parse.o: $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h include/htj2k_amd.h
 $(CSRC)/htj2k_device.o: $(CSRC)/htj2k_device.hip $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h include/htj2k_amd.h $(wildcard $(CSRC)/*.hpp)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -g -fPIC -ffp-contract=off -std=c++17 -Wall $(HIPFLAGS_EXTRA) -c $< -o $@
 
-$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/j2k_parse.o
+$(CSRC)/htj2k_pipe.o: $(CSRC)/htj2k_pipe.cpp include/htj2k_amd.h
+	$(CXX) -O2 -g -fPIC -std=c++17 -Wall -pthread -c $< -o $@
+
+$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 # The oracle links the same host parser object as the product (parsing is not on the

@@ -76,7 +76,9 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
            "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
-           "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes"]
+           "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes",
+           "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
+           "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free"]
 
 _lib = None
 
@@ -93,6 +95,9 @@ def load_library():
         L.htj2k_device_name.restype = ctypes.c_char_p
         L.htj2k_device_name.argtypes = [ctypes.c_void_p]
         L.htj2k_job_device_plane.restype = ctypes.c_void_p
+        L.htj2k_host_alloc.restype = ctypes.c_void_p
+        L.htj2k_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.htj2k_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -106,6 +111,11 @@ def _check(r, what):
 def _pkt(data):
     # AVPacket data carries AV_INPUT_BUFFER_PADDING_SIZE (64) zero bytes of padding (libavcodec/defs.h:40)
     return ctypes.create_string_buffer(bytes(data) + b"\0" * 64, len(data) + 64)
+
+
+def packet(data):
+    """(padded ctypes buffer, size): a packet that can be sent many times without re-copying it in Python"""
+    return _pkt(data), len(data)
 
 
 class Job:
@@ -124,9 +134,10 @@ class Job:
     def parse_batch(self, datas):
         """several independent frames -> one job whose stages are single launches over the whole batch"""
         n = len(datas)
-        self._bufs = [_pkt(d) for d in datas]
+        pk = [d if isinstance(d, tuple) else packet(d) for d in datas]       # packet(): padded ctypes buffer, reusable
+        self._bufs = [b for b, _ in pk]
         ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p) for b in self._bufs])
-        sizes = (ctypes.c_int * n)(*[len(d) for d in datas])
+        sizes = (ctypes.c_int * n)(*[sz for _, sz in pk])
         _check(self.dec.L.htj2k_job_parse_batch(self.dec.h, ptrs, sizes, n, ctypes.byref(self.h)), "htj2k_job_parse_batch")
         return self
 
@@ -233,6 +244,53 @@ def planes_to_arrays(info, planes):
     return out
 
 
+EAGAIN = -11
+
+
+class Pipe:
+    """htj2k_pipe_*: packets in, frames out (in order), `depth` batches of `batch` frames in flight"""
+
+    def __init__(self, dec, batch=8, depth=3):
+        self.dec = dec
+        self.h = ctypes.c_void_p(None)
+        _check(dec.L.htj2k_pipe_open(dec.h, batch, depth, ctypes.byref(self.h)), "htj2k_pipe_open")
+
+    def send(self, data):
+        """False when `depth` batches are waiting to be received.  `data`: bytes, or a (ctypes buffer, size) pair
+        from packet() -- building the padded buffer costs two copies of the packet in Python"""
+        if isinstance(data, tuple):                        # caller keeps the buffer alive: no copy in the library either
+            buf, size = data
+            r = self.dec.L.htj2k_pipe_send_ref(self.h, buf, size, None, None)
+        else:
+            r = self.dec.L.htj2k_pipe_send(self.h, _pkt(data), len(data))
+        if r == EAGAIN:
+            return False
+        _check(r, "htj2k_pipe_send")
+        return True
+
+    def flush(self):
+        _check(self.dec.L.htj2k_pipe_flush(self.h), "htj2k_pipe_flush")
+
+    def receive(self, into=None):
+        """-> (info, [plane arrays]) of the next frame, None when nothing is in flight; raises for a
+        packet that failed (Htj2kError; the frame is consumed).  `into` = (planes, Frame) from alloc_frame to reuse buffers."""
+        info = Info()
+        r = self.dec.L.htj2k_pipe_info(self.h, ctypes.byref(info))
+        if r == EAGAIN:
+            return None
+        if r < 0:
+            self.dec.L.htj2k_pipe_skip(self.h)
+            _check(r, "htj2k_pipe_info")
+        planes, fr = into if into is not None else alloc_frame(info)
+        _check(self.dec.L.htj2k_pipe_receive(self.h, ctypes.byref(fr)), "htj2k_pipe_receive")
+        return info, planes_to_arrays(info, planes)
+
+    def close(self):
+        if self.h:
+            self.dec.L.htj2k_pipe_close(self.h)
+            self.h = ctypes.c_void_p(None)
+
+
 class Decoder:
     """htj2k_open / htj2k_probe / htj2k_decode / htj2k_close: the FFCodec init/decode/close trio."""
 
@@ -265,6 +323,29 @@ class Decoder:
 
     def set_int(self, name, value):
         _check(self.L.htj2k_set_int(self.h, name.encode(), int(value)), "htj2k_set_int")
+
+    def pipe(self, batch=8, depth=3):
+        return Pipe(self, batch, depth)
+
+    def alloc_frame_pinned(self, info):
+        """frame planes in page-locked host memory (htj2k_host_alloc); free with free_frame_pinned"""
+        planes, fr, ptrs = [], Frame(), []
+        for p in range(info.nplanes):
+            ls = info.plane_width[p] * info.plane_bytes_per_sample[p]
+            n = ls * info.plane_height[p]
+            ptr = self.L.htj2k_host_alloc(self.h, n)
+            if not ptr:
+                raise MemoryError("htj2k_host_alloc")
+            ptrs.append(ptr)
+            a = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr)).reshape(info.plane_height[p], ls)
+            planes.append(a)
+            fr.data[p] = ptr
+            fr.linesize[p] = ls
+        return (planes, fr), ptrs
+
+    def free_frame_pinned(self, ptrs):
+        for ptr in ptrs:
+            self.L.htj2k_host_free(self.h, ptr)
 
     def probe(self, data):
         info = Info()

@@ -13,7 +13,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/htj2k_amd.h"
@@ -46,6 +49,26 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct HostBuf {                       /* pinned host memory (async H2D at PCIe rate), grow-only */
+    void *p = nullptr;
+    size_t cap = 0;
+    int device = 0;
+    void *ensure(size_t n)
+    {
+        if (n <= cap) return p;
+        /* called from the parse threads: bind the thread to the device only when something has to be
+         * allocated (the first HIP call of a fresh thread costs milliseconds) */
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+        cap = want;
+        return p;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct htj2k_ctx {
     htj2k_opts opts;
     int device = 0;
@@ -60,6 +83,8 @@ struct htj2k_ctx {
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
+    int parse_threads = 0;             /* host threads that parse the frames of a batch; 0 = min(cores, 16) */
+    std::mutex log_mutex;
 };
 
 struct LevelLaunch {                   /* one IDWT launch: all planes (of all frames) of one type that have this level */
@@ -78,6 +103,7 @@ struct FrameSlot {                     /* one frame of a batch */
     J2kParser *parser = nullptr;
     const J2kPlan *plan = nullptr;
     std::vector<uint8_t> pkt;          /* private copy: the caller's packet is only borrowed for the call */
+    HostBuf h_bytes;                   /* the parser gathers the codeblock bytes straight into pinned memory */
     uint32_t block_base = 0, tc_base = 0, sample_base = 0;
     size_t bytes_base = 0;
     DevBuf d_out[4];
@@ -131,7 +157,10 @@ static void clog(htj2k_ctx *c, int level, const char *fmt, ...)
 static void parser_log_tramp(void *opaque, int level, const char *msg)
 {
     htj2k_ctx *c = (htj2k_ctx *)opaque;
-    if (c && c->log) c->log(c->log_opaque, level, msg);
+    if (c && c->log) {
+        std::lock_guard<std::mutex> lk(c->log_mutex);      /* frames of a batch are parsed by several threads */
+        c->log(c->log_opaque, level, msg);
+    }
 }
 
 #define HIP_TRY(c, expr)                                                                      \
@@ -219,6 +248,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!c || !name) return HTJ2K_ERR_EINVAL;
     if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (!strcmp(name, "fuse_pack")) { c->fuse_pack = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
@@ -226,6 +256,20 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
 }
 
 extern "C" const char *htj2k_device_name(htj2k_ctx *c) { return c ? c->devname : ""; }
+
+extern "C" void *htj2k_host_alloc(htj2k_ctx *c, size_t size)
+{
+    void *p = nullptr;
+    if (!c || !size || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void htj2k_host_free(htj2k_ctx *c, void *ptr)
+{
+    (void)c;
+    if (ptr) (void)hipHostFree(ptr);
+}
 
 extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
 {
@@ -238,6 +282,7 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
+        f.h_bytes.release();
     }
     for (int i = 0; i < 6; i++) if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
     for (hipEvent_t e : j->lev_ev) if (e) (void)hipEventDestroy(e);
@@ -305,9 +350,40 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
             if (!F.parser) return HTJ2K_ERR_ENOMEM;
             j2k_parser_set_log(F.parser, parser_log_tramp, c);
         }
+        /* the codeblock bytes are gathered straight into pinned memory: the H2D copy of the upload
+         * then runs at PCIe rate and truly asynchronously (re-registered on every call: the
+         * FrameSlot may have moved when the vector grew) */
+        F.h_bytes.device = c->device;
+        j2k_parser_set_bytes_alloc(F.parser, [](void *opaque, size_t nb) -> void * { return ((HostBuf *)opaque)->ensure(nb); },
+                                   &F.h_bytes);
         F.plan = nullptr;
-        int r = j2k_parse(F.parser, pkts[f], sizes[f], &c->opts, 0, &F.plan);
-        if (r < 0) return r;
+    }
+    /* frames are independent: parse them on several host threads */
+    {
+        std::vector<int> rc(n, 0);
+        int nthreads = c->parse_threads > 0 ? c->parse_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (nthreads > n) nthreads = n;
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int f = next.fetch_add(1);
+                if (f >= n) break;
+                rc[f] = j2k_parse(j->frames[f].parser, pkts[f], sizes[f], &c->opts, 0, &j->frames[f].plan);
+            }
+        };
+        if (nthreads <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool) t.join();
+        }
+        for (int f = 0; f < n; f++)
+            if (rc[f] < 0) return rc[f];                   /* the first failing frame in submission order */
+    }
+    for (int f = 0; f < n; f++) {
+        FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
         if (nsamples + pl->nsamples > 0xFFFFFF00ull || nbytes + pl->nbytes > 0xFFFFFF00ull ||
             j->tilecomps.size() + pl->ntilecomps > 250)      /* J2kBlock.tcomp is a byte */
@@ -377,6 +453,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 /* LDS windows of the HT kernel are sized from the largest cleanup prefix / suffix, quad row
  * and (for blocks with refinement passes) state bitmap in the table */
+static int ht_lds_layout(htj2k_ctx *c, uint32_t max_p, uint32_t max_s, uint32_t max_qw, uint32_t bm_words, HtLds *out, HtLds *out_ext);
+
+/* LDS sizing from a block table + byte pool (unit entry point; jobs take the figures from the plans) */
 static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const uint8_t *const *bases,
                         const uint32_t *base_of_block, HtLds *out, HtLds *out_ext = nullptr)
 {
@@ -400,6 +479,11 @@ static int build_ht_lds(htj2k_ctx *c, const J2kBlock *blocks, int nblocks, const
             if (wds > bm_words) bm_words = wds;
         }
     }
+    return ht_lds_layout(c, max_p, max_s, max_qw, bm_words, out, out_ext);
+}
+
+static int ht_lds_layout(htj2k_ctx *c, uint32_t max_p, uint32_t max_s, uint32_t max_qw, uint32_t bm_words, HtLds *out, HtLds *out_ext)
+{
     HtLds &L = *out;
     size_t off = 4096;                                   /* the two CxtVLC tables */
     L.ms_words = (max_p * 8 + 31) / 32 + 3;
@@ -669,26 +753,36 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     int r;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        std::vector<const uint8_t *> bases(j->nframes);
-        std::vector<uint32_t> bob(j->blocks.size());
-        std::vector<J2kBlock> rel(j->blocks.size());
+        uint32_t max_p = 0, max_s = 2, max_qw = 1, bm_words = 0;
         for (int f = 0; f < j->nframes; f++) {
-            const FrameSlot &F = j->frames[f];
-            bases[f] = F.plan->bytes;
-            for (int i = 0; i < F.plan->nblocks; i++) { bob[F.block_base + i] = f; rel[F.block_base + i] = F.plan->blocks[i]; }
+            const J2kPlan *pl = j->frames[f].plan;
+            max_p = std::max(max_p, pl->max_pcup); max_s = std::max(max_s, pl->max_scup);
+            max_qw = std::max(max_qw, pl->max_qw); bm_words = std::max(bm_words, pl->max_bm_words);
         }
-        if ((r = build_ht_lds(c, rel.data(), (int)rel.size(), bases.data(), bob.data(), &j->lds, &j->lds_ext)) < 0) return r;
+        if ((r = ht_lds_layout(c, max_p, max_s, max_qw, bm_words, &j->lds, &j->lds_ext)) < 0) return r;
         j->max_qw = j->lds.max_qw;
     }
     {
-        /* blocks are independent: order the table by quad count so that the 64 lanes of a k_ht_vlc
-         * wave (one lane per block) run similar trip counts; then lay the quad-symbol arrays out */
-        std::stable_sort(j->blocks.begin(), j->blocks.end(), [](const J2kBlock &a, const J2kBlock &b) {
-            const int ka = a.npasses ? ((a.w + 1) >> 1) * ((a.h + 1) >> 1) : 0;
-            const int kb = b.npasses ? ((b.w + 1) >> 1) * ((b.h + 1) >> 1) : 0;
-            if (ka != kb) return ka > kb;
-            return a.w > b.w;
-        });
+        /* blocks are independent: order the table by quad count (then width), largest first, so that
+         * the 64 lanes of a k_ht_vlc wave (one lane per block) run similar trip counts; then lay the
+         * quad-symbol arrays out.  Two stable counting passes (least significant key first). */
+        auto quads = [](const J2kBlock &b) { return b.npasses ? (uint32_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1) : 0u; };
+        const size_t nb = j->blocks.size();
+        std::vector<J2kBlock> tmp(nb);
+        {
+            std::vector<uint32_t> cnt(1026, 0);
+            for (const J2kBlock &b : j->blocks) cnt[1024 - std::min<uint32_t>(b.w, 1024) + 1]++;
+            for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+            for (const J2kBlock &b : j->blocks) tmp[cnt[1024 - std::min<uint32_t>(b.w, 1024)]++] = b;
+        }
+        {
+            uint32_t maxq = 0;
+            for (const J2kBlock &b : tmp) maxq = std::max(maxq, quads(b));
+            std::vector<uint32_t> cnt((size_t)maxq + 2, 0);
+            for (const J2kBlock &b : tmp) cnt[maxq - quads(b) + 1]++;
+            for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+            for (const J2kBlock &b : tmp) j->blocks[cnt[maxq - quads(b)]++] = b;
+        }
         j->qoff.resize(j->blocks.size() + 1);
         size_t q = 0;
         for (size_t i = 0; i < j->blocks.size(); i++) {

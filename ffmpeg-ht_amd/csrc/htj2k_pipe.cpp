@@ -1,0 +1,244 @@
+/*
+ * htj2k_pipe.cpp -- packets in, frames out: the asynchronous face of the decoder.
+ *
+ * The reference gets its throughput from FFmpeg's frame threads: N decoder contexts, one packet
+ * each (libavcodec/pthread_frame.c:856-889).  On a GPU the equivalent is to keep `depth` device
+ * jobs of `batch` frames each in flight: while job i runs its kernels, the host threads parse
+ * job i+1 (frames are independent: htj2k_job_parse_batch parses them in parallel, straight into
+ * pinned memory) and the caller copies the frames of job i-1 out.  Host parsing, PCIe and the
+ * kernels then overlap instead of adding up.
+ *
+ * Only the public C ABI of include/htj2k_amd.h is used here.  Frames come back in the order
+ * their packets went in.  A packet that does not parse fails the batch it is in; the frames of
+ * such a batch are then decoded one by one, so that only the bad packet reports an error --
+ * the same per-packet error behaviour as the synchronous htj2k_decode().
+ */
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include <string.h>
+
+#include "../../include/htj2k_amd.h"
+
+namespace {
+
+constexpr int PIPE_PAD = 64;           /* AV_INPUT_BUFFER_PADDING_SIZE: the private packet copies carry it */
+
+enum SlotState { SLOT_FREE, SLOT_FILLING, SLOT_RUNNING, SLOT_DONE };
+
+struct Packet {                        /* either a private copy or a reference the caller keeps alive */
+    const uint8_t *data = nullptr;
+    int size = 0;
+    uint8_t *own = nullptr;
+    void (*release)(void *) = nullptr;
+    void *opaque = nullptr;
+    void drop()
+    {
+        if (release) release(opaque);
+        delete[] own;
+        data = nullptr; own = nullptr; release = nullptr; size = 0;
+    }
+};
+
+struct Slot {
+    htj2k_job *job = nullptr;
+    std::vector<Packet> pkts;
+    SlotState state = SLOT_FREE;
+    int rc = 0;                        /* result of the batch run */
+    int next_out = 0;                  /* next frame of the batch to hand out */
+    std::thread worker;
+};
+
+}  // namespace
+
+struct htj2k_pipe {
+    htj2k_ctx *ctx = nullptr;
+    int batch = 1, depth = 2;
+    std::vector<Slot> slots;
+    int fill = 0, out = 0;             /* ring positions: slot being filled / slot being handed out */
+    std::mutex m;
+    std::condition_variable cv;
+    htj2k_job *single = nullptr;       /* per-frame retry of a failed batch */
+};
+
+static void run_slot(htj2k_pipe *p, Slot *s)
+{
+    std::vector<const uint8_t *> ptr(s->pkts.size());
+    std::vector<int> len(s->pkts.size());
+    for (size_t i = 0; i < s->pkts.size(); i++) { ptr[i] = s->pkts[i].data; len[i] = s->pkts[i].size; }
+    int r = htj2k_job_parse_batch(p->ctx, ptr.data(), len.data(), (int)ptr.size(), &s->job);
+    if (r >= 0) r = htj2k_job_upload(p->ctx, s->job);
+    if (r >= 0) r = htj2k_job_run(p->ctx, s->job);
+    if (r >= 0) r = htj2k_job_wait(p->ctx, s->job);
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        s->rc = r;
+        s->state = SLOT_DONE;
+    }
+    p->cv.notify_all();
+}
+
+/* caller holds the lock */
+static void start_slot(htj2k_pipe *p, Slot &s)
+{
+    s.state = SLOT_RUNNING;
+    s.rc = 0;
+    s.next_out = 0;
+    if (s.worker.joinable()) s.worker.join();
+    s.worker = std::thread(run_slot, p, &s);
+}
+
+extern "C" int htj2k_pipe_open(htj2k_ctx *ctx, int batch, int depth, htj2k_pipe **pipe)
+{
+    if (!ctx || !pipe || batch < 1 || batch > 256 || depth < 1 || depth > 16) return HTJ2K_ERR_EINVAL;
+    htj2k_pipe *p = new (std::nothrow) htj2k_pipe();
+    if (!p) return HTJ2K_ERR_ENOMEM;
+    p->ctx = ctx;
+    p->batch = batch;
+    p->depth = depth;
+    p->slots.resize(depth);
+    *pipe = p;
+    return 0;
+}
+
+static int queue_packet(htj2k_pipe *p, const Packet &pk)
+{
+    Slot &s = p->slots[p->fill];
+    s.pkts.push_back(pk);
+    s.state = SLOT_FILLING;
+    if ((int)s.pkts.size() >= p->batch) {
+        start_slot(p, s);
+        p->fill = (p->fill + 1) % p->depth;
+    }
+    return 0;
+}
+
+extern "C" int htj2k_pipe_send(htj2k_pipe *p, const uint8_t *pkt, int size)
+{
+    if (!p || !pkt || size <= 0) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot &s = p->slots[p->fill];
+    if (s.state != SLOT_FREE && s.state != SLOT_FILLING) return HTJ2K_ERR_EAGAIN;      /* receive first */
+    /* private copy with the input padding an AVPacket carries (AV_INPUT_BUFFER_PADDING_SIZE) */
+    Packet pk;
+    pk.own = new (std::nothrow) uint8_t[(size_t)size + PIPE_PAD];
+    if (!pk.own) return HTJ2K_ERR_ENOMEM;
+    memcpy(pk.own, pkt, (size_t)size);
+    memset(pk.own + size, 0, PIPE_PAD);
+    pk.data = pk.own;
+    pk.size = size;
+    return queue_packet(p, pk);
+}
+
+/* no copy: `pkt` stays valid until `release(opaque)` is called, which happens when the packet's
+ * frame has been received or skipped (or the pipe is closed) -- what an AVPacket reference gives */
+extern "C" int htj2k_pipe_send_ref(htj2k_pipe *p, const uint8_t *pkt, int size, void (*release)(void *), void *opaque)
+{
+    if (!p || !pkt || size <= 0) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot &s = p->slots[p->fill];
+    if (s.state != SLOT_FREE && s.state != SLOT_FILLING) return HTJ2K_ERR_EAGAIN;
+    Packet pk;
+    pk.data = pkt;
+    pk.size = size;
+    pk.release = release;
+    pk.opaque = opaque;
+    return queue_packet(p, pk);
+}
+
+extern "C" int htj2k_pipe_flush(htj2k_pipe *p)
+{
+    if (!p) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot &s = p->slots[p->fill];
+    if (s.state == SLOT_FILLING) {
+        start_slot(p, s);
+        p->fill = (p->fill + 1) % p->depth;
+    }
+    return 0;
+}
+
+/* the slot whose frame is due; waits for its job.  HTJ2K_ERR_EAGAIN: nothing is in flight (send or flush first) */
+static int due_slot(htj2k_pipe *p, std::unique_lock<std::mutex> &lk, Slot **out)
+{
+    Slot &s = p->slots[p->out];
+    if (s.state == SLOT_FREE || s.state == SLOT_FILLING) return HTJ2K_ERR_EAGAIN;
+    p->cv.wait(lk, [&] { return s.state == SLOT_DONE; });
+    *out = &s;
+    return 0;
+}
+
+static void pop_frame(htj2k_pipe *p, Slot &s)
+{
+    s.pkts[s.next_out].drop();
+    if (++s.next_out >= (int)s.pkts.size()) {
+        s.pkts.clear();
+        s.next_out = 0;
+        s.state = SLOT_FREE;
+        p->out = (p->out + 1) % p->depth;
+    }
+}
+
+extern "C" int htj2k_pipe_info(htj2k_pipe *p, htj2k_info *info)
+{
+    if (!p || !info) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot *s = nullptr;
+    int r = due_slot(p, lk, &s);
+    if (r < 0) return r;
+    if (s->rc >= 0) return htj2k_job_frame_info(s->job, s->next_out, info);
+    /* failed batch: the per-frame retry in htj2k_pipe_receive decides; probe this packet alone */
+    const Packet &pk = s->pkts[s->next_out];
+    return htj2k_probe(p->ctx, pk.data, pk.size, info);
+}
+
+extern "C" int htj2k_pipe_receive(htj2k_pipe *p, htj2k_frame *frame)
+{
+    if (!p || !frame) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot *s = nullptr;
+    int r = due_slot(p, lk, &s);
+    if (r < 0) return r;
+    /* a finished slot belongs to the (single) consumer: copy out without holding the lock, so
+     * that the workers of the other slots and htj2k_pipe_send are not held up by the D2H */
+    lk.unlock();
+    if (s->rc >= 0) {
+        r = htj2k_job_download_frame(p->ctx, s->job, s->next_out, frame);
+    } else {
+        const Packet &pk = s->pkts[s->next_out];
+        r = htj2k_job_parse(p->ctx, pk.data, pk.size, &p->single);
+        if (r >= 0) r = htj2k_job_upload(p->ctx, p->single);
+        if (r >= 0) r = htj2k_job_run(p->ctx, p->single);
+        if (r >= 0) r = htj2k_job_download(p->ctx, p->single, frame);
+    }
+    lk.lock();
+    pop_frame(p, *s);
+    return r;
+}
+
+/* drop the next frame without copying it out (e.g. after htj2k_pipe_info reported an error) */
+extern "C" int htj2k_pipe_skip(htj2k_pipe *p)
+{
+    if (!p) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot *s = nullptr;
+    int r = due_slot(p, lk, &s);
+    if (r < 0) return r;
+    pop_frame(p, *s);
+    return 0;
+}
+
+extern "C" void htj2k_pipe_close(htj2k_pipe *p)
+{
+    if (!p) return;
+    for (Slot &s : p->slots) {
+        if (s.worker.joinable()) s.worker.join();
+        if (s.job) htj2k_job_free(p->ctx, s.job);
+        for (size_t i = (s.state == SLOT_FREE ? s.pkts.size() : (size_t)s.next_out); i < s.pkts.size(); i++) s.pkts[i].drop();
+    }
+    if (p->single) htj2k_job_free(p->ctx, p->single);
+    delete p;
+}

@@ -74,7 +74,7 @@ static inline uint32_t gb_peek_be32(const GB *g) { return gb_left(g) < 4 ? 0 : (
 typedef struct Chunk { struct Chunk *next; size_t cap, used; } Chunk;
 typedef struct Arena { Chunk *head; Chunk *cur; } Arena;
 
-static void *arena_alloc(Arena *a, size_t n)
+static void *arena_alloc_raw(Arena *a, size_t n, int zero)
 {
     n = (n + 15) & ~(size_t)15;
     for (;;) {
@@ -82,7 +82,7 @@ static void *arena_alloc(Arena *a, size_t n)
         if (c && c->cap - c->used >= n) {
             void *p = (uint8_t *)(c + 1) + c->used;
             c->used += n;
-            memset(p, 0, n);
+            if (zero) memset(p, 0, n);
             return p;
         }
         if (c && c->next) { a->cur = c->next; a->cur->used = 0; continue; }
@@ -96,6 +96,7 @@ static void *arena_alloc(Arena *a, size_t n)
         }
     }
 }
+static void *arena_alloc(Arena *a, size_t n) { return arena_alloc_raw(a, n, 1); }
 static void arena_reset(Arena *a) { a->cur = a->head; if (a->cur) a->cur->used = 0; }
 static void arena_free(Arena *a) { Chunk *c = a->head; while (c) { Chunk *n = c->next; free(c); c = n; } a->head = a->cur = NULL; }
 
@@ -186,6 +187,7 @@ typedef struct Tile {
 struct J2kParser {
     Arena arena;
     j2k_log_fn log; void *log_opaque;
+    j2k_bytes_alloc_fn bytes_alloc; void *bytes_alloc_opaque;
     htj2k_opts opts;
     GB g;
     int width, height, image_offset_x, image_offset_y, tile_offset_x, tile_offset_y;
@@ -2457,10 +2459,14 @@ static int build_plan(J2kParser *s)
     pl->ntilecomps = ntiles * s->ncomponents;
     pl->tilecomps  = (J2kTileComp *)arena_alloc(&s->arena, (size_t)pl->ntilecomps * sizeof(J2kTileComp));
     pl->blocks     = (J2kBlock *)arena_alloc(&s->arena, (nblocks ? nblocks : 1) * sizeof(J2kBlock));
-    pl->bytes      = (uint8_t *)arena_alloc(&s->arena, nbytes + 64);
+    /* the byte pool is written exactly once below (block bytes + zeroed pads): no memset of the
+     * whole pool, and the device layer may hand out pinned memory for it */
+    pl->bytes      = s->bytes_alloc ? (uint8_t *)s->bytes_alloc(s->bytes_alloc_opaque, nbytes + 64)
+                                    : (uint8_t *)arena_alloc_raw(&s->arena, nbytes + 64, 0);
     if (!pl->tilecomps || !pl->blocks || !pl->bytes)
         return HTJ2K_ERR_ENOMEM;
     pl->max_lcup = pl->max_lref = 0;
+    pl->max_pcup = 0; pl->max_scup = 2; pl->max_qw = 1; pl->max_bm_words = 0;
 
     for (tileno = 0; tileno < ntiles; tileno++) {
         Tile *tile = s->tile + tileno;
@@ -2591,10 +2597,26 @@ static int build_plan(J2kParser *s)
                                 o += sg->len;
                             }
                             boff += ((size_t)c->length + 8 + 15) & ~(size_t)15;
+                            memset(pl->bytes + o, 0, boff - o);        /* the pad behind the block */
                             if (c->npasses) {
+                                uint32_t qw = ((uint32_t)bw + 1u) >> 1;
+                                int rem = c->npasses % 3, plhd = rem ? c->npasses - rem : c->npasses - 3;
                                 t->coded = 1;
                                 if (b->lcup > pl->max_lcup) pl->max_lcup = b->lcup;
                                 if (b->lref > pl->max_lref) pl->max_lref = b->lref;
+                                if (qw > pl->max_qw) pl->max_qw = qw;
+                                if (b->lcup >= 2) {
+                                    const uint8_t *D = pl->bytes + b->data_off;
+                                    uint32_t scup = ((uint32_t)D[b->lcup - 1] << 4) + (D[b->lcup - 2] & 0x0F);
+                                    if (scup >= 2 && scup <= b->lcup && scup <= 4079) {
+                                        if (scup > pl->max_scup) pl->max_scup = scup;
+                                        if (b->lcup - scup > pl->max_pcup) pl->max_pcup = b->lcup - scup;
+                                    }
+                                }
+                                if (c->npasses - plhd > 1) {
+                                    uint32_t wds = ((uint32_t)(bw + 2) * (uint32_t)(bh + 2) + 31) / 32 + 1;
+                                    if (wds > pl->max_bm_words) pl->max_bm_words = wds;
+                                }
                             }
                         }
                     }
@@ -2602,6 +2624,7 @@ static int build_plan(J2kParser *s)
             }
         }
     }
+    memset(pl->bytes + boff, 0, 64);
     pl->nblocks  = nb;
     pl->nbytes   = boff;
     pl->nsamples = nsamples;
@@ -2646,6 +2669,12 @@ void j2k_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque)
     p->log_opaque = opaque;
 }
 
+void j2k_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque)
+{
+    p->bytes_alloc = fn;
+    p->bytes_alloc_opaque = opaque;
+}
+
 /* jpeg2000_decode_frame, jpeg2000dec.c:2825-2908, up to (not including) execute2() */
 int j2k_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts,
               int headers_only, const J2kPlan **plan)
@@ -2653,6 +2682,8 @@ int j2k_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts
     Arena arena = s->arena;
     j2k_log_fn lg = s->log;
     void *lo = s->log_opaque;
+    j2k_bytes_alloc_fn ba = s->bytes_alloc;
+    void *bao = s->bytes_alloc_opaque;
     int ret, tileno;
 
     /* jpeg2000_dec_cleanup() leaves a zeroed context between frames (jpeg2000dec.c:2397-2423) */
@@ -2660,6 +2691,8 @@ int j2k_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts
     s->arena = arena;
     s->log = lg;
     s->log_opaque = lo;
+    s->bytes_alloc = ba;
+    s->bytes_alloc_opaque = bao;
     arena_reset(&s->arena);
     if (opts)
         s->opts = *opts;
@@ -2681,7 +2714,7 @@ int j2k_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts
     if (gb_left(&s->g) >= 12 &&
         (gb_be32u(&s->g) == 12) && (gb_be32u(&s->g) == TAG('j', 'P', ' ', ' ')) &&
         (gb_be32u(&s->g) == 0x0D0A870A)) {
-        if (jp2_find_codestream(s) <= 0) {
+        if (!jp2_find_codestream(s)) {             /* a negative return counts as found, as in jpeg2000dec.c:2846 */
             plog(s, LOG_ERROR, "Could not find Jpeg2000 codestream atom.\n");
             return HTJ2K_ERR_INVALIDDATA;
         }

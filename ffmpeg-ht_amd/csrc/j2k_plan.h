@@ -85,6 +85,11 @@ typedef struct J2kPlan {
     size_t   nbytes;
     size_t   nsamples;           /* total samples of all planes (frame coefficient buffer size) */
     uint32_t max_lcup, max_lref; /* sizing of the per-wave LDS windows */
+    /* over the coded blocks with a valid cleanup segment: longest MagSgn (Pcup) and VLC/MEL (Scup) parts,
+     * widest block in quads, largest refinement bitmap ((w+2)*(h+2) bits in words, blocks with > 1 pass).
+     * Computed while the block bytes are hot in cache, so that the device layer never has to touch the
+     * byte pool again (jpeg2000htdec.c:1252-1273 for the Scup rules) */
+    uint32_t max_pcup, max_scup, max_qw, max_bm_words;
     uint32_t palette[256];
 } J2kPlan;
 
@@ -95,6 +100,10 @@ typedef void (*j2k_log_fn)(void *opaque, int level, const char *msg);
 J2kParser *j2k_parser_new(void);
 void       j2k_parser_free(J2kParser *p);
 void       j2k_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque);
+/* where J2kPlan.bytes of the next plans lives: fn(opaque, n) returns a buffer of >= n bytes that stays
+ * valid until its next call (the device layer hands out pinned host memory); NULL fn = the parser's arena */
+typedef void *(*j2k_bytes_alloc_fn)(void *opaque, size_t n);
+void       j2k_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque);
 
 /* Full parse: markers + all packets.  `headers_only` stops after the main
  * header (info valid, no blocks), like skip_frame >= AVDISCARD_ALL

@@ -32,6 +32,7 @@ extern "C" {
 #define HTJ2K_ERR_PATCHWELCOME  (-0x45574150) /* AVERROR_PATCHWELCOME = -MKTAG('P','A','W','E') */
 #define HTJ2K_ERR_BUG           (-0x21475542) /* AVERROR_BUG          = -MKTAG('B','U','G','!') */
 #define HTJ2K_ERR_EXTERNAL      (-0x20545845) /* AVERROR_EXTERNAL     = -MKTAG('E','X','T',' ') : HIP runtime failure */
+#define HTJ2K_ERR_EAGAIN        (-11)         /* AVERROR(EAGAIN): pipeline: send more / receive first */
 #define HTJ2K_ERR_ENOMEM        (-12)         /* AVERROR(ENOMEM) */
 #define HTJ2K_ERR_EINVAL        (-22)         /* AVERROR(EINVAL) */
 #define HTJ2K_ERR_ENOSYS        (-38)         /* AVERROR(ENOSYS): no usable gfx950 device */
@@ -198,8 +199,41 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
+ *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
  *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
+
+/* Pinned (page-locked) host memory for frame planes: a D2H copy into it runs at PCIe rate (about 5x a
+ * copy into pageable memory).  An integration wraps it in its buffer pool, e.g. av_buffer_create()
+ * with htj2k_host_free as the free callback.  Plain pageable planes work everywhere, only slower. */
+void *htj2k_host_alloc(htj2k_ctx *ctx, size_t size);
+void  htj2k_host_free(htj2k_ctx *ctx, void *ptr);
+
+/* ---- asynchronous pipeline: packets in, frames out, in order (csrc/htj2k_pipe.cpp) ----
+ * The throughput path for a stream of frames.  It takes the place of FFmpeg's frame threads
+ * (libavcodec/pthread_frame.c:856-889: N decoder contexts, one packet each) and maps onto
+ * FFCodec.cb.receive_frame: `depth` device jobs of `batch` frames are kept in flight, so that host
+ * parsing (on several threads, see "parse_threads"), PCIe transfers and kernels overlap.
+ *   htj2k_pipe_send     queues a copy of the packet; HTJ2K_ERR_EAGAIN when `depth` batches are
+ *                       waiting to be received
+ *   htj2k_pipe_flush    starts the partly filled batch (end of stream, or latency matters)
+ *   htj2k_pipe_info     what the next frame will be (blocks until its batch is decoded);
+ *                       HTJ2K_ERR_EAGAIN when nothing is in flight
+ *   htj2k_pipe_receive  copies the next frame into the caller's planes; a packet that failed
+ *                       returns its own error, the other frames of its batch are still delivered
+ *   htj2k_pipe_skip     drops the next frame
+ * One producer/consumer thread at a time may use a pipe (like an AVCodecContext). */
+typedef struct htj2k_pipe htj2k_pipe;
+int  htj2k_pipe_open(htj2k_ctx *ctx, int batch, int depth, htj2k_pipe **pipe);
+int  htj2k_pipe_send(htj2k_pipe *pipe, const uint8_t *pkt, int size);
+/* as htj2k_pipe_send without the copy: `pkt` (with its 64 bytes of input padding) stays valid until
+ * release(opaque) is called -- when the packet's frame has been received or skipped, or on close */
+int  htj2k_pipe_send_ref(htj2k_pipe *pipe, const uint8_t *pkt, int size, void (*release)(void *opaque), void *opaque);
+int  htj2k_pipe_flush(htj2k_pipe *pipe);
+int  htj2k_pipe_info(htj2k_pipe *pipe, htj2k_info *info);
+int  htj2k_pipe_receive(htj2k_pipe *pipe, htj2k_frame *out);
+int  htj2k_pipe_skip(htj2k_pipe *pipe);
+void htj2k_pipe_close(htj2k_pipe *pipe);
 
 const char *htj2k_version(void);
 /* name of the device the context is bound to, e.g. "gfx950" */

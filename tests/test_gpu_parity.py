@@ -135,6 +135,56 @@ def test_batch_job_of_mixed_frames(dec, orc, fuse):
         dec.set_int("fuse_pack", 1)
 
 
+def test_pipeline_in_order_with_bad_packets(dec, orc):
+    """htj2k_pipe_*: frames come back in send order, bit-identical to the oracle; a packet that does
+    not parse costs its own frame only (the rest of its batch is decoded one by one)"""
+    import ffmpeg_ht_amd as m
+    names = [n for n in sorted(streams.CASES) if not streams.get(n)[1]]
+    pkts = [streams.get(n)[0] for n in names]
+    good = pkts[0]
+    items = []                                           # (packet, expect_ok)
+    for i, p in enumerate(pkts):
+        items.append((p, True))
+        if i == 5:
+            items.append((b"\x00\x01garbage" * 9, False))
+        if i == 9:
+            items.append((good[:len(good) // 3], False))  # truncated body
+    pipe = dec.pipe(batch=4, depth=2)
+    try:
+        got, sent = [], 0
+        def drain_one():
+            try:
+                r = pipe.receive()
+            except m.Htj2kError as e:
+                got.append(("err", e.code))
+                return True
+            if r is None:
+                return False
+            got.append(r)
+            return True
+        keep = [m.packet(pkt) for pkt, _ in items]        # odd packets go in by reference (htj2k_pipe_send_ref)
+        for i, (pkt, _) in enumerate(items):
+            while not pipe.send(keep[i] if i & 1 else pkt):
+                assert drain_one()
+            sent += 1
+        pipe.flush()
+        while len(got) < sent:
+            assert drain_one()
+        assert pipe.receive() is None
+    finally:
+        pipe.close()
+    assert len(got) == len(items)
+    for (pkt, ok), g in zip(items, got):
+        if not ok:
+            assert g[0] == "err" and g[1] < 0
+            continue
+        info, planes = g
+        info_o, planes_o, _ = orc.decode(pkt)
+        assert (info.width, info.height, info.pix_fmt) == (info_o.width, info_o.height, info_o.pix_fmt)
+        for a, b in zip(planes, planes_o):
+            assert np.array_equal(a, b)
+
+
 def test_idwt_random_borders(dec):
     """the reference's own DWT unit test shape (libavcodec/tests/jpeg2000dwt.c): random
     borders incl. odd origins, 1..3 sample lines, levels deeper than the size allows"""
