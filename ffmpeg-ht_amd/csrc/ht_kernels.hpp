@@ -240,16 +240,16 @@ __device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict_
 
 template <int TRANSFORM, bool REFINE>
 __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
-                                                     uint32_t *__restrict__ dst, uint32_t *bm, int lane, int w, int h,
+                                                     uint32_t *__restrict__ dst, int lane, int w, int h,
                                                      int stride, int pLSB, int maxbp, int M_b, float fscale, int i_step,
-                                                     uint32_t last_wi, uint32_t *__restrict__ sink)
+                                                     uint32_t last_wi, uint32_t *__restrict__ sink,
+                                                     const uint64_t *__restrict__ rb, int z_blk)
 {
     const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
     const int col = lane;
     const bool act = col < 2 * qw;                         /* lanes past the block read qi = 0: no bits, exponent 0 */
     const bool st_ok = col < w;
     const int q = col >> 1, sh = (col & 1) * 2;
-    const int bmW = w + 2;
     const int dshift = 31 - M_b;
     const uint32_t half = 1u << ((pLSB - 1) & 31);
     uint32_t ms_pos = 0, Eb = 0;
@@ -301,15 +301,24 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
         Eb = m_b != 0 ? (uint32_t)(32 - __clz((int)(vb | 1))) : 0u;
         const bool two = 2 * row + 1 < h;                  /* odd heights: the outside half of the last quad row is discarded (:976-1007) */
         if (REFINE) {
-            if (st_ok) {
-                const int y0 = 2 * row;
-                prow[0] = mu_t;
-                if (s_t) atomicOr(&bm[((y0 + 1) * bmW + col + 1) >> 5], 1u << (((y0 + 1) * bmW + col + 1) & 31));
-                if (two) {
-                    prow[stride] = mu_b;
-                    if (s_b) atomicOr(&bm[((y0 + 2) * bmW + col + 1) >> 5], 1u << (((y0 + 2) * bmW + col + 1) & 31));
-                }
-            }
+            /* the SigProp / MagRef decisions of k_ht_refine, three 64-bit masks per sample row (newly
+             * significant, its sign, MagRef bit), applied before the dequantisation: both passes work
+             * on bit-plane pLSB - 1 (jpeg2000htdec.c:1309-1315, :1066-1100, :1160-1185) */
+            const int qq = (pLSB - 1) & 31;
+            const uint64_t *r = rb + 6 * row;              /* rows 2 * row and 2 * row + 1 */
+            const uint64_t Rt = r[0], Gt = r[1], Qt = r[2];
+            uint64_t Rb = 0, Gb = 0, Qb = 0;
+            if (two) { Rb = r[3]; Gb = r[4]; Qb = r[5]; }
+            auto refine = [&](uint32_t v, uint32_t sig, uint64_t R, uint64_t G, uint64_t Q) -> uint32_t {
+                const uint32_t nsig = (uint32_t)(R >> col) & 1u, sgn = (uint32_t)(G >> col) & 1u, mrb = (uint32_t)(Q >> col) & 1u;
+                if (nsig) v |= (1u << qq) | (1u << ((qq - 1) & 31)) | (sgn << 31);
+                if (z_blk > 2 && sig) { v &= (0xFFFFFFFEu | mrb) << qq; v |= 1u << ((qq - 1) & 31); }
+                return v;
+            };
+            const uint32_t o_t = ht_dequant(refine(mu_t, s_t, Rt, Gt, Qt), TRANSFORM, M_b, 0, fscale, i_step);
+            const uint32_t o_b = ht_dequant(refine(mu_b, s_b, Rb, Gb, Qb), TRANSFORM, M_b, 0, fscale, i_step);
+            *(st_ok ? prow : sink) = o_t;
+            *((st_ok && two) ? prow + stride : sink) = o_b;
         } else {
             uint32_t o_t, o_b;
             if (TRANSFORM == J2K_DWT53) {
@@ -352,7 +361,7 @@ __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
             int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
-            uint32_t *__restrict__ sink)
+            uint32_t *__restrict__ sink, const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -418,7 +427,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         for (int i = lane; i < 2 * Estride; i += 64) Earr[i] = 0;
         for (uint32_t i = lane; i < 2 * L.max_qw; i += 64) qinfo[i] = 0;
     }
-    if (z_blk > 1)
+    if (z_blk > 1 && !fast)
         for (uint32_t i = lane; i < 4 * L.bm_words; i += 64) bm[i] = 0;
     __syncthreads();
 
@@ -477,15 +486,16 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     int ctx_run = 0;                                   /* first-row context carried along the row */
     const int bmW = w + 2;                             /* bitmap row pitch (1-cell border) */
 
+    const uint64_t *rbits = (fast && z_blk > 1 && refbits) ? refbits + roff[blockIdx.x] : nullptr;
     if (fast) {
         if (z_blk > 1) {
-            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
-            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
-            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
         } else {
-            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
-            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
-            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, false>(qglob, ms, dst, bm, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink);
+            if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
+            else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
+            else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, false>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
         }
     }
     for (int row = 0; row < qh && !err && !fast; row++) {
@@ -646,7 +656,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         if (lane == 0) status[blockIdx.x] = err;
         return;
     }
-    if (z_blk <= 1) return;
+    if (z_blk <= 1 || fast) return;                    /* the fast path applied k_ht_refine's decisions in its row loop */
 
     /* ---- stage 3: refinement passes on bitmaps (bit index = (y+1)*(w+2) + x+1) ---- */
     uint32_t *bm_sig = bm, *bm_ref = bm + L.bm_words, *bm_sgn = bm + 2 * L.bm_words, *bm_mr = bm + 3 * L.bm_words;
@@ -754,6 +764,81 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
  * k_ht_decode<true> (wave per block)  MagSgn + dequantisation + refinement passes.
  * The host sorts the block table by size so that the 64 lanes of a k_ht_vlc wave run similar
  * trip counts. */
+/* Backward byte stream (VLC, MagRef): bytes top[0], top[-1], ... top[-(n-1)] in read order, four per lane and
+ * pass.  A byte whose 7 LSBs are set loses its MSB when the byte read before it is > 0x8F
+ * (jpeg2000htdec.c:145-201); the byte "before" the first one is 0xFF.  `first_or` is ORed into the first
+ * byte (the VLC stream's Dcup[Lcup-2] counts with its low nibble set, :1277-1278).  `out` (LDS) is zeroed. */
+__device__ __forceinline__ uint32_t ht_unstuff_backward(const uint8_t *__restrict__ top, uint32_t n, uint32_t first_or,
+                                                        uint32_t *out, int lane)
+{
+    uint32_t base = 0, carry = 0xFF;
+    for (uint32_t k0 = 0; k0 < n; k0 += 256) {
+        const uint32_t k = k0 + 4 * lane;                /* read index of r0 */
+        const int nv = min(max((int)n - (int)k, 0), 4);
+        uint32_t dw = 0;
+        if (nv > 0) __builtin_memcpy(&dw, top - k - 3, 4);     /* up to 3 bytes in front of the stream: block bytes or pad */
+        uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
+        if (k == 0) r0 |= first_or;
+        if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
+        uint32_t above = ht_dpp_left(r3);
+        if (lane == 0) above = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
+        const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+        const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+        const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+        const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+        const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
+                               ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
+        const uint32_t incl = wave_incl_scan_u32(tot, lane);
+        const uint32_t off = base + incl - tot, sh = off & 31;
+        if (nv > 0) {
+            atomicOr(&out[off >> 5], chunk << sh);
+            if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
+        }
+        base += wave_last(incl);
+    }
+    return base;
+}
+
+/* Forward LSB-first stream whose bytes after 0xFF carry 7 bits, the MSB dropped (SigProp,
+ * jpeg2000htdec.c:1016-1131): bytes src[0..n), any alignment.  `out` (LDS) is zeroed. */
+__device__ __forceinline__ uint32_t ht_unstuff_forward7(const uint8_t *__restrict__ src, uint32_t n, uint32_t *out, int lane)
+{
+    uint32_t base = 0, carry = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + 4 * lane;
+        const int nv = min(max((int)n - (int)i, 0), 4);
+        uint32_t dw = 0;
+        if (nv > 0) __builtin_memcpy(&dw, src + i, 4);
+        if (nv < 4) dw &= nv ? (0xFFFFFFFFu >> (32 - 8 * nv)) : 0u;
+        const uint32_t b0 = dw & 0xFF, b1 = (dw >> 8) & 0xFF, b2 = (dw >> 16) & 0xFF, b3 = dw >> 24;
+        uint32_t prev = ht_dpp_left(b3);
+        if (lane == 0) prev = carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)b3, 63);
+        const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n1 = nv > 1 ? (b0 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n2 = nv > 2 ? (b1 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t n3 = nv > 3 ? (b2 == 0xFF ? 7u : 8u) : 0u;
+        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+        const uint32_t chunk = (b0 & ((1u << n0) - 1)) | ((b1 & ((1u << n1) - 1)) << o1) |
+                               ((b2 & ((1u << n2) - 1)) << o2) | ((b3 & ((1u << n3) - 1)) << o3);
+        const uint32_t incl = wave_incl_scan_u32(tot, lane);
+        const uint32_t off = base + incl - tot, sh = off & 31;
+        if (nv > 0) {
+            atomicOr(&out[off >> 5], chunk << sh);
+            if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
+        }
+        base += wave_last(incl);
+    }
+    return base;
+}
+
+/* words of the un-stuffed arrays of one block: [0, ht_nsw) VLC resp. MEL, [ht_nsw, ht_nsw + ht_nsp) SigProp
+ * resp. MagRef (blocks with refinement passes); both fit the block's byte region (J2K_BLOCK_PAD) */
+__host__ __device__ inline uint32_t ht_nsw(uint32_t Scup) { return (Scup * 8 + 31) / 32 + 2; }
+__host__ __device__ inline uint32_t ht_nsp(uint32_t Lref) { return (Lref * 8 + 31) / 32 + 3; }
+
 __global__ void __launch_bounds__(64)
 k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
              uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u, uint32_t lds_words)
@@ -768,7 +853,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     const uint32_t Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
     if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
     const uint32_t Pcup = Lcup - Scup;
-    const uint32_t nsw = (Scup * 8 + 31) / 32 + 2;
+    const uint32_t nsw = ht_nsw(Scup);
     if (2 * nsw > lds_words) return;                     /* host sized the LDS from the same fields */
     uint32_t *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
     uint32_t *sv = sw, *sm = sw + nsw;
@@ -776,44 +861,8 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     for (uint32_t i = lane; i < 2 * nsw; i += 64) sw[i] = 0;
     __syncthreads();
 
-    /* ---- VLC: backward from Dcup[Lcup-2]; four bytes per lane and pass, in read order
-     * r0 = Dcup[j] .. r3 = Dcup[j-3].  Dcup[Lcup-2] counts with its low nibble set (:1277-1278);
-     * a byte whose 7 LSBs are set loses its MSB when the byte read before it is > 0x8F
-     * (:145-201), the byte "before" the first one being 0xFF. ---- */
-    {
-        uint32_t base = 0, carry = 0xFF;
-        const uint32_t nvb = Scup - 1;                   /* bytes Lcup-2 .. Pcup */
-        for (uint32_t k0 = 0; k0 < nvb; k0 += 256) {
-            const uint32_t k = k0 + 4 * lane;            /* read index of r0 */
-            const int nv = min(max((int)nvb - (int)k, 0), 4);
-            uint32_t dw = 0;
-            if (nv > 0) {                                /* Dcup[j-3 .. j], j = Lcup-2-k; the 16 bytes in front of the
-                                                          * first block of the buffer are padding (j2k_parse.c) */
-                const uint8_t *p = D + (Lcup - 2 - k) - 3;
-                __builtin_memcpy(&dw, p, 4);
-            }
-            uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
-            if (k == 0) r0 |= 0x0F;
-            if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
-            uint32_t above = ht_dpp_left(r3);
-            if (lane == 0) above = carry;
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
-            const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-            const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-            const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-            const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-            const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
-            const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
-                                   ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
-            const uint32_t incl = wave_incl_scan_u32(tot, lane);
-            const uint32_t off = base + incl - tot, sh = off & 31;
-            if (nv > 0) {
-                atomicOr(&sv[off >> 5], chunk << sh);
-                if (sh) atomicOr(&sv[(off >> 5) + 1], chunk >> (32 - sh));
-            }
-            base += wave_last(incl);
-        }
-    }
+    /* ---- VLC: backward from Dcup[Lcup-2] ---- */
+    ht_unstuff_backward(D + Lcup - 2, Scup - 1, 0x0F, sv, lane);
 
     /* ---- MEL: forward from Dcup[Pcup], MSB-first; Dcup[Lcup-1] counts as 0xFF, Dcup[Lcup-2] with
      * its low nibble set; a byte after 0xFF has 7 bits (:429-440) ---- */
@@ -824,7 +873,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
             const uint32_t i = i0 + 4 * lane;
             const int nv = min(max((int)Scup - (int)i, 0), 4);
             uint32_t dw = 0;
-            if (nv > 0) __builtin_memcpy(&dw, D + Pcup + i, 4);      /* the block's 8 trailing pad bytes cover the tail */
+            if (nv > 0) __builtin_memcpy(&dw, D + Pcup + i, 4);      /* the block's trailing pad bytes cover the tail */
             uint32_t m[4] = { dw & 0xFF, (dw >> 8) & 0xFF, (dw >> 16) & 0xFF, dw >> 24 };
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -864,6 +913,164 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
         if (i * 32 >= mel_bits) v = 0xFFFFFFFFu;
         else if (i * 32 + 32 > mel_bits) v |= 0xFFFFFFFFu >> (mel_bits & 31);
         meO[i] = v;
+    }
+
+    /* ---- refinement segment (blocks with more than the cleanup pass): SigProp forward, MagRef backward
+     * over Dref = Dcup + Lcup (:1016-1185, :1260); zero bits past either end ---- */
+    const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+    if (b.npasses - plhd > 1 && b.lref > 0) {
+        const uint32_t Lref = b.lref, nsp = ht_nsp(Lref);
+        if (2 * nsp > lds_words) return;
+        uint32_t *ss = sw, *sr = sw + nsp;
+        __syncthreads();
+        for (uint32_t i = lane; i < 2 * nsp; i += 64) sw[i] = 0;
+        __syncthreads();
+        ht_unstuff_forward7(D + Lcup, Lref, ss, lane);
+        ht_unstuff_backward(D + Lcup + Lref - 1, Lref, 0, sr, lane);
+        __syncthreads();
+        for (uint32_t i = lane; i < nsp; i += 64) {
+            vlO[nsw + i] = ss[i];
+            meO[nsw + i] = sr[i];
+        }
+    }
+}
+
+/* ================================================================== k_ht_refine
+ * SigProp and MagRef decisions (jpeg2000htdec.c:1016-1185) of the blocks that carry refinement
+ * passes, one LANE per block.  Both passes are serial chains through the block -- which sample
+ * takes the next stream bit depends on the significance the previous bits created -- so, as with
+ * the VLC chain, the parallelism is across blocks: 64 chains per wavefront instead of one chain
+ * on lane 0 of a wavefront that idles its other 63 lanes.
+ * Significance is kept as one 64-bit mask per sample row (blocks up to 64 columns; wider ones stay
+ * with k_ht_decode's own serial pass): the 3x3 neighbourhood test is three shifts and an OR.
+ * Input bits: the un-stuffed SigProp / MagRef arrays of k_ht_unstuff (zero bits past either end).
+ * Output: three masks per row -- newly significant, its sign, MagRef bit -- which k_ht_decode
+ * applies while it dequantises.  ref_list[i] = block index, roff[block] = first mask of the block. */
+__global__ void __launch_bounds__(64)
+k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ ref_list, int nref,
+            const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
+            const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u,
+            uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
+{
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nref) return;
+    const uint32_t bi = ref_list[li];
+    const J2kBlock b = blocks[bi];
+    const int w = b.w, h = b.h, qw = (w + 1) >> 1, qh = (h + 1) >> 1;
+    uint64_t *out = refbits + roff[bi];
+    for (int y = 0; y < 3 * h; y++) out[y] = 0;                       /* also what an invalid block leaves behind */
+    if (b.npasses == 0 || b.lcup < 2 || w > 64) return;
+    const uint8_t *D = bytes + b.data_off;
+    const uint32_t Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
+    if (Scup < 2 || Scup > b.lcup || Scup > 4079) return;
+    const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+    const int z_blk = b.npasses - plhd;
+    if (z_blk <= 1) return;
+    const bool causal = (b.flags & J2K_CBLK_VSC) != 0;
+    const uint32_t *qs = qsym + qoff[bi];
+    const uint32_t nsw = ht_nsw(Scup), nsp = b.lref ? ht_nsp(b.lref) : 0;
+    const uint32_t *spw = vlc_u + (b.data_off >> 2) + nsw, *mrw = mel_u + (b.data_off >> 2) + nsw;
+    const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+
+    /* LSB-first readers over the un-stuffed arrays: a 64-bit buffer topped up a word at a time, the
+     * word for the next top-up already in flight.  Past the array: zero bits. */
+    struct Bits {
+        const uint32_t *p; uint32_t n, idx; uint64_t buf; int cnt; uint32_t nxt;
+        __device__ __forceinline__ void init(const uint32_t *q, uint32_t nw)
+        {
+            p = q; n = nw; idx = 0; buf = 0; cnt = 0;
+            nxt = n ? p[0] : 0u; idx = 1;
+        }
+        __device__ __forceinline__ void top_up()                     /* call with cnt <= 32 */
+        {
+            buf |= (uint64_t)nxt << cnt;
+            cnt += 32;
+            nxt = idx < n ? p[idx] : 0u;
+            idx++;
+        }
+        __device__ __forceinline__ uint32_t get()
+        {
+            const uint32_t bit = (uint32_t)buf & 1u;
+            buf >>= 1; cnt--;
+            return bit;
+        }
+    } sp, mr;
+    sp.init(spw, nsp);
+    mr.init(mrw, nsp);
+
+    auto quad_rows = [&](int qy, uint64_t &top, uint64_t &bot) {
+        top = 0; bot = 0;
+        if (qy >= qh) return;
+        const uint32_t *row = qs + (size_t)qy * qw;
+        for (int q = 0; q < qw; q++) {
+            const uint32_t rho = row[q] & 15u;
+            top |= (uint64_t)((rho & 1u) | ((rho >> 1) & 2u)) << (2 * q);            /* samples 0, 2 of the quad */
+            bot |= (uint64_t)(((rho >> 1) & 1u) | ((rho >> 2) & 2u)) << (2 * q);     /* samples 1, 3 */
+        }
+        top &= wmask; bot &= wmask;
+        if (2 * qy + 1 >= h) bot = 0;
+    };
+    auto win = [](uint64_t x, int j) -> uint32_t {                   /* bits j-1, j, j+1 */
+        return (uint32_t)(j ? (x >> (j - 1)) : (x << 1)) & 7u;
+    };
+
+    uint64_t a_top, a_bot;
+    quad_rows(0, a_top, a_bot);
+    uint64_t Mup = 0;                                                  /* significance of the row above the stripe, after its SigProp */
+    for (int i0 = 0; i0 < h; i0 += 4) {
+        uint64_t b_top, b_bot, c_top, c_bot;
+        quad_rows(i0 / 2 + 1, b_top, b_bot);
+        quad_rows(i0 / 2 + 2, c_top, c_bot);
+        const uint64_t S0 = a_top, S1 = a_bot, S2 = b_top, S3 = b_bot, S4 = c_top;
+        uint64_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0, Q0 = 0, Q1 = 0, Q2 = 0, Q3 = 0;
+        const int gh = min(4, h - i0);
+        for (int j0 = 0; j0 < w; j0 += 4) {
+            if (sp.cnt <= 32) sp.top_up();                             /* a 4x4 group takes at most 32 bits */
+#define HT_SIGPROP_SAMPLE(ii, SC, RC, UP, DN)                                                           \
+            if (ii < gh && !((SC >> j) & 1)) {                                                            \
+                const bool below_ok = !causal || ii != gh - 1;                                            \
+                const uint32_t mbr = win(UP, j) | (win(SC | RC, j) & 5u) | (below_ok ? win(DN, j) : 0u);  \
+                if (mbr && sp.get()) RC |= 1ull << j;                                                     \
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = j0 + jj;
+                if (j < w) {
+                    HT_SIGPROP_SAMPLE(0, S0, R0, Mup, (S1 | R1))
+                    HT_SIGPROP_SAMPLE(1, S1, R1, (S0 | R0), (S2 | R2))
+                    HT_SIGPROP_SAMPLE(2, S2, R2, (S1 | R1), (S3 | R3))
+                    HT_SIGPROP_SAMPLE(3, S3, R3, (S2 | R2), S4)
+                }
+            }
+#undef HT_SIGPROP_SAMPLE
+            /* signs of the samples this group made significant, same order (:1085-1100) */
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = j0 + jj;
+                if (j < w) {
+                    if ((R0 >> j) & 1) G0 |= (uint64_t)sp.get() << j;
+                    if ((R1 >> j) & 1) G1 |= (uint64_t)sp.get() << j;
+                    if ((R2 >> j) & 1) G2 |= (uint64_t)sp.get() << j;
+                    if ((R3 >> j) & 1) G3 |= (uint64_t)sp.get() << j;
+                }
+            }
+        }
+        if (z_blk > 2) {                                               /* MagRef: one bit per sample the cleanup pass made significant */
+            for (int j = 0; j < w; j++) {
+                if (mr.cnt <= 32) mr.top_up();
+                if ((S0 >> j) & 1) Q0 |= (uint64_t)mr.get() << j;
+                if ((S1 >> j) & 1) Q1 |= (uint64_t)mr.get() << j;
+                if ((S2 >> j) & 1) Q2 |= (uint64_t)mr.get() << j;
+                if ((S3 >> j) & 1) Q3 |= (uint64_t)mr.get() << j;
+            }
+        }
+        uint64_t *o = out + 3 * i0;
+        o[0] = R0; o[1] = G0; o[2] = Q0;
+        if (gh > 1) { o[3] = R1; o[4] = G1; o[5] = Q1; }
+        if (gh > 2) { o[6] = R2; o[7] = G2; o[8] = Q2; }
+        if (gh > 3) { o[9] = R3; o[10] = G3; o[11] = Q3; }
+        Mup = S3 | R3;
+        a_top = c_top; a_bot = c_bot;
     }
 }
 

@@ -123,8 +123,11 @@ struct htj2k_job {
     std::vector<hipEvent_t> lev_ev;    /* per-IDWT-launch brackets (roofline measurement) */
     int lev_ev_used = 0;
     std::vector<double> lev_bytes, lev_hbm;   /* algorithmic / least-HBM bytes of each recorded launch */
-    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_vlcu, d_melu;
+    DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_vlcu, d_melu, d_reflist, d_roff, d_refbits;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
+    std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
+    size_t nrefmasks = 0;
+    uint32_t max_lref = 0;
     size_t nquads = 0;
     HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
     uint32_t max_qw = 1;
@@ -278,7 +281,7 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     if (j->stream) (void)hipStreamSynchronize(j->stream);
     j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
     j->d_t0.release(); j->d_t1.release(); j->d_desc.release(); j->d_qsym.release(); j->d_qoff.release();
-    j->d_vlcu.release(); j->d_melu.release();
+    j->d_vlcu.release(); j->d_melu.release(); j->d_reflist.release(); j->d_roff.release(); j->d_refbits.release();
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
@@ -761,6 +764,8 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
         if ((r = ht_lds_layout(c, max_p, max_s, max_qw, bm_words, &j->lds, &j->lds_ext)) < 0) return r;
         j->max_qw = j->lds.max_qw;
+        j->max_lref = 0;
+        for (int f = 0; f < j->nframes; f++) j->max_lref = std::max(j->max_lref, j->frames[f].plan->max_lref);
     }
     {
         /* blocks are independent: order the table by quad count (then width), largest first, so that
@@ -792,6 +797,22 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
         if (q > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
         j->nquads = q;
+        /* blocks with SigProp / MagRef passes go through k_ht_refine (one lane per block) when
+         * k_ht_decode's row-mask path can take them: up to 64 columns, no ROI shift */
+        j->reflist.clear();
+        j->roff.assign(j->blocks.size() + 1, 0);
+        size_t nm = 0;
+        for (size_t i = 0; i < j->blocks.size(); i++) {
+            const J2kBlock &b = j->blocks[i];
+            const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+            j->roff[i] = (uint32_t)nm;
+            if (b.npasses && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
+                j->reflist.push_back((uint32_t)i);
+                nm += (size_t)3 * b.h;
+            }
+        }
+        if (nm > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
+        j->nrefmasks = nm;
     }
     const size_t coef_bytes = (j->nsamples + 64) * sizeof(uint32_t);
     const int nblocks = (int)j->blocks.size();
@@ -804,6 +825,9 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_qsym.ensure((j->nquads + 64) * sizeof(uint32_t))) < 0) return r;
     if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
     if ((r = j->d_vlcu.ensure(j->nbytes + 256)) < 0 || (r = j->d_melu.ensure(j->nbytes + 256)) < 0) return r;
+    if ((r = j->d_reflist.ensure((j->reflist.size() + 1) * sizeof(uint32_t))) < 0 ||
+        (r = j->d_roff.ensure(j->roff.size() * sizeof(uint32_t))) < 0 ||
+        (r = j->d_refbits.ensure((j->nrefmasks + 8) * sizeof(uint64_t))) < 0) return r;
     for (int f = 0; f < j->nframes; f++) {
         FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
@@ -829,6 +853,9 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if (nblocks) {
         HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, j->blocks.data(), (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
         HIP_TRY(c, hipMemcpyAsync(j->d_qoff.p, j->qoff.data(), j->qoff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+        HIP_TRY(c, hipMemcpyAsync(j->d_roff.p, j->roff.data(), j->roff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+        if (!j->reflist.empty())
+            HIP_TRY(c, hipMemcpyAsync(j->d_reflist.p, j->reflist.data(), j->reflist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
     }
     HIP_TRY(c, hipEventRecord(j->ev[1], j->stream));
     j->uploaded = 1;
@@ -975,7 +1002,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
-                const uint32_t us_words = 2 * j->lds.vlc_words;
+                const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
                 const uint32_t us_lds = us_words * 4;
                 if (us_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
@@ -986,18 +1013,26 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, 0);
+                if (!j->reflist.empty())
+                    hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, (const uint32_t *)j->d_reflist.p, (int)j->reflist.size(),
+                                       (const uint8_t *)j->d_bytes.p, (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                       (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
+                                       (uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
                                    (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
-                                   (uint32_t *)j->d_coef.p + j->nsamples + 32);
+                                   (uint32_t *)j->d_coef.p + j->nsamples + 32,
+                                   (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
             } else {
                 if ((int)j->lds.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
                 hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)j->d_coef.p + j->nsamples + 32);
+                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)j->d_coef.p + j->nsamples + 32,
+                                   (const uint64_t *)nullptr, (const uint32_t *)nullptr);
             }
             HIP_TRY(c, hipGetLastError());
         }
@@ -1395,7 +1430,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     if (!c || !blocks_in || nblocks <= 0 || !bytes_in || !coef) return HTJ2K_ERR_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     /* the kernels want the layout j2k_parse.c produces: every block's bytes at a 16-byte aligned
-     * offset, 8+ pad bytes behind them and 16 in front of the first: re-pack the caller's pool */
+     * offset, J2K_BLOCK_PAD bytes behind them and 16 in front of the first: re-pack the caller's pool */
     std::vector<J2kBlock> blk((const J2kBlock *)blocks_in, (const J2kBlock *)blocks_in + nblocks);
     std::vector<uint8_t> pool(16, 0);
     for (int i = 0; i < nblocks; i++) {
@@ -1403,7 +1438,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         const size_t len = (size_t)b.lcup + b.lref;
         if ((size_t)b.data_off + len > nbytes_in) return HTJ2K_ERR_EINVAL;
         const size_t o = pool.size();
-        pool.resize(o + ((len + 8 + 15) & ~(size_t)15), 0);
+        pool.resize(o + J2K_BLOCK_REGION(len), 0);
         memcpy(pool.data() + o, bytes_in + b.data_off, len);
         b.data_off = (uint32_t)o;
     }
@@ -1421,15 +1456,32 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         qoff[i] = (uint32_t)nq;
         if (b.npasses) nq += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
     }
-    DevBuf db, dby, dc, ds, dq, dqo, du[2];
-    if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
-        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0) {
-        dq.release(); dqo.release(); du[0].release(); du[1].release();
-        return r;
+    /* blocks with refinement passes that k_ht_refine handles (same rule as htj2k_job_upload) */
+    std::vector<uint32_t> reflist, roff(nblocks + 1, 0);
+    size_t nmasks = 0;
+    uint32_t max_lref = 0;
+    for (int i = 0; i < nblocks; i++) {
+        const J2kBlock &b = ((const J2kBlock *)blocks)[i];
+        const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+        roff[i] = (uint32_t)nmasks;
+        if (b.lref > max_lref) max_lref = b.lref;
+        if (b.npasses && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
+            reflist.push_back((uint32_t)i);
+            nmasks += (size_t)3 * b.h;
+        }
     }
-    if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
-        (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0) {
+    DevBuf db, dby, dc, ds, dq, dqo, du[2], drl, dro, drb;
+    auto release_all = [&]() {
         db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release();
+        drl.release(); dro.release(); drb.release();
+    };
+    if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
+        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 ||
+        (r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
+        (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0 ||
+        (r = drl.ensure((reflist.size() + 1) * 4)) < 0 || (r = dro.ensure(roff.size() * 4)) < 0 ||
+        (r = drb.ensure((nmasks + 8) * 8)) < 0) {
+        release_all();
         return r;
     }
     hipError_t e = hipMemcpy(db.p, blocks, (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice);
@@ -1437,6 +1489,8 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
     if (e == hipSuccess) e = hipMemcpy(dqo.p, qoff.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dro.p, roff.data(), roff.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !reflist.empty()) e = hipMemcpy(drl.p, reflist.data(), reflist.size() * 4, hipMemcpyHostToDevice);
     const size_t vlc_lds = 4096 + 1024 + HT_VSTAGE_BYTES + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
@@ -1444,7 +1498,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         if (e == hipSuccess && (int)tmp.ext.total > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
-            const uint32_t us_words = 2 * tmp.lds.vlc_words;
+            const uint32_t us_words = 2 * std::max(tmp.lds.vlc_words, reflist.empty() ? 0u : ht_nsp(max_lref));
             const uint32_t us_lds = us_words * 4;
             if (us_lds > 48 * 1024)
                 (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
@@ -1453,9 +1507,15 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
             hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, 0);
+            if (!reflist.empty())
+                hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
+                                   (const J2kBlock *)db.p, (const uint32_t *)drl.p, (int)reflist.size(), (const uint8_t *)dby.p,
+                                   (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p,
+                                   (uint64_t *)drb.p, (const uint32_t *)dro.p);
             hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), tmp.ext.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.ext,
-                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (uint32_t *)dc.p + nsamples + 8);
+                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (uint32_t *)dc.p + nsamples + 8,
+                               (const uint64_t *)drb.p, (const uint32_t *)dro.p);
             e = hipDeviceSynchronize();
         }
     } else if (e == hipSuccess) {
@@ -1464,14 +1524,15 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)dc.p + nsamples + 8);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)dc.p + nsamples + 8,
+                               (const uint64_t *)nullptr, (const uint32_t *)nullptr);
             e = hipDeviceSynchronize();
         }
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
-    db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release();
+    release_all();
     if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_ht_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
     return 0;
 }

@@ -2448,7 +2448,7 @@ static int build_plan(J2kParser *s)
                             if (c->coord[0][1] <= c->coord[0][0] || c->coord[1][1] <= c->coord[1][0])
                                 continue;
                             nblocks++;
-                            nbytes += ((size_t)c->length + 8 + 15) & ~(size_t)15;
+                            nbytes += J2K_BLOCK_REGION(c->length);
                         }
                     }
                 }
@@ -2596,7 +2596,7 @@ static int build_plan(J2kParser *s)
                                 memcpy(pl->bytes + o, sg->src, sg->len);
                                 o += sg->len;
                             }
-                            boff += ((size_t)c->length + 8 + 15) & ~(size_t)15;
+                            boff += J2K_BLOCK_REGION(c->length);
                             memset(pl->bytes + o, 0, boff - o);        /* the pad behind the block */
                             if (c->npasses) {
                                 uint32_t qw = ((uint32_t)bw + 1u) >> 1;

@@ -93,6 +93,12 @@ typedef struct J2kPlan {
     uint32_t palette[256];
 } J2kPlan;
 
+/* bytes kept free behind every block's Dcup||Dref in J2kPlan.bytes (regions are 16-byte aligned): the device
+ * kernels read whole dwords up to the end of a segment, and the un-stuffed copies of a block's VLC/MEL and
+ * SigProp/MagRef streams (k_ht_unstuff) share one region of the same size: (Scup + Lref) / 4 + 7 words at most */
+#define J2K_BLOCK_PAD 32
+#define J2K_BLOCK_REGION(len) ((((size_t)(len)) + J2K_BLOCK_PAD + 15) & ~(size_t)15)
+
 typedef struct J2kParser J2kParser;   /* reusable arena; not thread-safe */
 
 typedef void (*j2k_log_fn)(void *opaque, int level, const char *msg);
