@@ -46,6 +46,11 @@ struct HtLds {
 #define HT_VSTAGE_PITCH 28                  /* dwords per lane: 24 staged + pad; 7 x 16 B keeps b128 writes conflict-free */
 #define HT_VSTAGE_BYTES (64 * HT_VSTAGE_PITCH * 4)
 
+/* quad symbols of a block in d_qsym: rows padded to an even number of quads (k_ht_vlc emits two
+ * per pass of its loop), the block rounded up to 16 words (its lanes flush 64-byte chunks) */
+__host__ __device__ inline uint32_t ht_qsym_pitch(uint32_t w) { return (((w + 1) >> 1) + 1) & ~1u; }
+__host__ __device__ inline uint32_t ht_qsym_words(uint32_t w, uint32_t h) { return (ht_qsym_pitch(w) * ((h + 1) >> 1) + 15) & ~15u; }
+
 /* inclusive prefix sum over the 64 lanes with DPP: Hillis-Steele inside each row of 16 lanes
  * (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3
  * (gfx9 DPP controls; lanes without a source keep `old` = 0) */
@@ -254,12 +259,13 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
     const uint32_t half = 1u << ((pLSB - 1) & 31);
     uint32_t ms_pos = 0, Eb = 0;
     int err = 0;
+    const int qwp = (int)ht_qsym_pitch((uint32_t)w);       /* k_ht_vlc pads the symbol rows to an even quad count */
     const uint32_t *qp = qglob + q;
     uint32_t qi_next = act ? *qp : 0u;
     uint32_t *prow = dst + col;                            /* this lane's column, row 2 * row */
     for (int row = 0; row < qh; row++) {
         const uint32_t qi = qi_next;
-        qp += qw;
+        qp += qwp;
         if (row + 1 < qh) qi_next = act ? *qp : 0u;
         const uint32_t rho = qi & 0xF, uq = (qi >> 16) & 0xFF;
         /* this lane's samples: top = bit sh, bottom = bit sh + 1 of rho / e_k / e_1 */
@@ -582,7 +588,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             const int col = c0 + lane;
             const bool act = col < ncols;
             const int q = col >> 1;
-            const uint32_t qi = act ? (EXTERNAL_VLC ? qglob[row * qw + q] : qcur[q]) : 0;
+            const uint32_t qi = act ? (EXTERNAL_VLC ? qglob[row * (int)ht_qsym_pitch((uint32_t)w) + q] : qcur[q]) : 0;
             const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
             int kappa = 1;
             if (row > 0 && act) {                      /* :855-885; Eprev[-1] and Eprev[ncols] are 0 */
@@ -1001,7 +1007,7 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     auto quad_rows = [&](int qy, uint64_t &top, uint64_t &bot) {
         top = 0; bot = 0;
         if (qy >= qh) return;
-        const uint32_t *row = qs + (size_t)qy * qw;
+        const uint32_t *row = qs + (size_t)qy * ht_qsym_pitch((uint32_t)w);
         for (int q = 0; q < qw; q++) {
             const uint32_t rho = row[q] & 15u;
             top |= (uint64_t)((rho & 1u) | ((rho >> 1) & 2u)) << (2 * q);            /* samples 0, 2 of the quad */
@@ -1104,22 +1110,39 @@ __host__ __device__ inline uint16_t ht_uvlc_entry(int mode, uint32_t v)
     return (uint16_t)(p1 | (p2 << 3) | (lp << 6) | (s1 << 9) | (s2 << 12));
 }
 
+/* LDS of k_ht_vlc beyond the two decode tables: staged VLC words, the output stage (16 quad
+ * symbols per lane, pitch 17) with the three words of flush bookkeeping per lane, and the
+ * significance bytes of the row above */
+#define HT_VLC_OUT_PITCH 17
+#define HT_VLC_OUT_BYTES (64 * (HT_VLC_OUT_PITCH + 3) * 4)
+__host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
+{
+    return 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES + (size_t)((((max_qw + 3) >> 2) | 1) << 2) * 64;
+}
+
 __global__ void __launch_bounds__(64)
 k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
          const uint16_t *__restrict__ g_tables, uint32_t *__restrict__ qsym,
          const uint32_t *__restrict__ qoff, uint32_t max_qw,
-         const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u, int dbg)
+         const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u, uint32_t *__restrict__ sink)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint16_t *tbl = (uint16_t *)smem;
     uint16_t *utbl = (uint16_t *)(smem + 4096);          /* HT_UVLC_ENTRIES entries */
-    /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
-     * dwords is odd so the 64 lanes hit distinct banks */
     /* VLC words of every lane staged through LDS: 24 dwords (96 contiguous bytes) per lane are
      * fetched once every 8 quad pairs and cover the 16 pairs after they are issued (16 x 38 bits
      * + 31 < 768), so a lane touches 1-2 cache lines per refill instead of per pair */
     uint32_t *vstage = (uint32_t *)(smem + 4096 + 1024);
-    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES;
+    /* output stage: the two quad symbols of a pass go to LDS; every 8 passes the wave writes the 64
+     * lanes' 64-byte chunks out together, 4 lanes per chunk with 16-byte stores.  A lane storing
+     * its own two dwords per pass made 128 separate line requests per pass and wave (every lane
+     * writes into a different block's symbol array): that address traffic, not arithmetic, was
+     * 40 % of this kernel's time. */
+    uint32_t *ostage = (uint32_t *)(smem + 4096 + 1024 + HT_VSTAGE_BYTES);
+    uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;
+    /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
+     * dwords is odd so the 64 lanes hit distinct banks */
+    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int lane = threadIdx.x;
     const int bi = blockIdx.x * 64 + lane;
@@ -1127,7 +1150,6 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
     for (int i = lane; i < HT_UVLC_ENTRIES; i += 64)
         utbl[i] = ht_uvlc_entry(i >> 6, (uint32_t)(i & 63));
-    __syncthreads();
 
     int qw = 0, qh = 0;
     uint32_t doff = 0;
@@ -1147,13 +1169,25 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             doff = b.data_off >> 2;
         }
     }
+    /* one flat loop, the same number of passes for every lane of the wave: lane-local (row, qx)
+     * walk the block's quad pairs; n_it passes produce output */
+    const int ppr = (qw + 1) >> 1;                        /* passes per quad row */
+    const int n_it = qh * ppr;
+    int max_it = n_it;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) max_it = max(max_it, __shfl_xor(max_it, o));
+    obase_lo[lane] = (uint32_t)(uintptr_t)qout;
+    obase_hi[lane] = (uint32_t)((uintptr_t)qout >> 32);
+    onit[lane] = (uint32_t)n_it;
+    __syncthreads();
+
     const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
     uint8_t *myrho = rho_rows + lane * pitch;
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
     uint32_t *vst = vstage + lane * HT_VSTAGE_PITCH;
+    uint32_t *ost = ostage + lane * HT_VLC_OUT_PITCH;
     uint4 nx[6];                                         /* words in flight for the refill after next */
     uint32_t sbase = 0, nbase = 0;                       /* word index of vst[0] / of nx[0] */
-    int it = 0;
     /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
      * up to six codewords (>= 6, typically >= 32 symbols) from the un-stuffed MEL bits */
@@ -1168,120 +1202,138 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             *(uint4 *)(vst + 4 * jx) = q;
         }
     }
-    int ctx_run = 0;
-    for (int row = 0; row < qh; row++) {
+    /* the wave writes window `win` (passes 8 win .. 8 win + 7) of all lanes: 4 lanes per 64-byte chunk */
+    auto flush = [&](int win) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c = 16 * p + (lane >> 2), part = lane & 3;
+            const uint32_t *src = ostage + c * HT_VLC_OUT_PITCH + 4 * part;
+            const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+            uint32_t *dst = (uint32_t *)(((uintptr_t)obase_hi[c] << 32) | obase_lo[c]) + (size_t)win * 16 + 4 * part;
+            /* chunks of lanes that are done (or never had a block) go to a scratch line: always four
+             * stores, so that the wait for the staged VLC words can be counted (vmcnt) */
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) u32x4 g_u32x4;    /* a global, not a FLAT, store */
+            u32x4 vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * 8) < onit[c] ? dst : sink + 4 * part) = vv;
+        }
+    };
+
+    int ctx_run = 0, row = 0, qx = 0;
+    int rho_left = 0, ral = 0, ra_next = 0;
+    for (int t = 0; t < max_it; t++) {
+        const bool active = t < n_it;
         const uint16_t *table = tbl + (row ? 1024 : 0);
         const bool row0 = row == 0;
-        int rho_left = 0, ral = 0;
-        int ra_next = row ? (int)myrho[0] : 0;           /* above quad 0 */
-        uint32_t *rowout = qout + (size_t)row * qw;
-        for (int qx = 0; qx < qw && !(dbg & 2); qx += 2) {
-            const bool pair = qx + 1 < qw;
-            /* loads for the NEXT iteration, based at the word of the current positions */
-            if ((it & 7) == 0) {
-                if (it) {                                /* words requested 8 pairs ago become the staged window */
+        const bool pair = qx + 1 < qw;
+        if ((t & 7) == 0) {
+            if (t) {                                     /* words requested 8 passes ago become the staged window */
 #pragma unroll
-                    for (int jx = 0; jx < 6; jx++) *(uint4 *)(vst + 4 * jx) = nx[jx];
-                    sbase = nbase;
-                }
-                nbase = vpos >> 5;
-#pragma unroll
-                for (int jx = 0; jx < 6; jx++) __builtin_memcpy(&nx[jx], vsrc + nbase + 4 * jx, 16);
+                for (int jx = 0; jx < 6; jx++) *(uint4 *)(vst + 4 * jx) = nx[jx];
+                sbase = nbase;
             }
-            it++;
-            if (mcnt < 3) {                              /* a pair uses at most 3 MEL symbols */
-                const uint32_t *pm = msrc + (mbit >> 5);
-                const uint32_t sh = mbit & 31;
-                /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36 */
-                uint64_t mw = ((uint64_t)pm[0] << 32) | pm[1];
-                mw = sh ? ((mw << sh) | ((uint64_t)pm[2] >> (32 - sh))) : mw;
+            nbase = vpos >> 5;
 #pragma unroll
-                for (int cw = 0; cw < 6; cw++) {
-                    const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
-                    const int b = (int)(mw >> 63);
-                    const int run = b ? (1 << eval) : (eval ? (int)((mw << 1) >> (64 - eval)) : 0);
-                    const int nsy = run + (b ? 0 : 1);
-                    if (mcnt + nsy <= 64) {              /* otherwise leave the codeword for the next refill */
-                        if (!b) msyms |= 1ull << ((mcnt + run) & 63);
-                        mcnt += nsy;
-                        const int used = b ? 1 : 1 + eval;
-                        mw <<= used; mbit += used;
-                        mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
-                    }
+            for (int jx = 0; jx < 6; jx++) __builtin_memcpy(&nx[jx], vsrc + nbase + 4 * jx, 16);
+            if (t) flush((t >> 3) - 1);                  /* behind the loads: nothing waits for these stores for 8 passes */
+        }
+        if (mcnt < 3) {                                  /* a pair uses at most 3 MEL symbols */
+            const uint32_t *pm = msrc + (mbit >> 5);
+            const uint32_t sh = mbit & 31;
+            /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36 */
+            uint64_t mw = ((uint64_t)pm[0] << 32) | pm[1];
+            mw = sh ? ((mw << sh) | ((uint64_t)pm[2] >> (32 - sh))) : mw;
+#pragma unroll
+            for (int cw = 0; cw < 6; cw++) {
+                const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
+                const int b = (int)(mw >> 63);
+                const int run = b ? (1 << eval) : (eval ? (int)((mw << 1) >> (64 - eval)) : 0);
+                const int nsy = run + (b ? 0 : 1);
+                if (mcnt + nsy <= 64) {                  /* otherwise leave the codeword for the next refill */
+                    if (!b) msyms |= 1ull << ((mcnt + run) & 63);
+                    mcnt += nsy;
+                    const int used = b ? 1 : 1 + eval;
+                    mw <<= used; mbit += used;
+                    mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
                 }
             }
-            uint64_t vwin;
-            {
-                const uint32_t off = vpos - (sbase << 5), kw = off >> 5, sh = off & 31;
-                const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
-                const uint64_t lo = ((uint64_t)a1 << 32) | a0;
-                vwin = sh ? ((lo >> sh) | ((uint64_t)a2 << (64 - sh))) : lo;
-            }
-            uint32_t m = (uint32_t)msyms, mused = 0;     /* next MEL symbols, LSB first */
-            uint32_t a = (uint32_t)vwin, aused = 0;     /* the two codewords need <= 14 bits */
-            int rho[2], uoff[2], ek[2], e1[2];
+        }
+        uint64_t vwin;
+        {
+            const uint32_t off = vpos - (sbase << 5), kw = off >> 5, sh = off & 31;
+            const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
+            const uint64_t lo = ((uint64_t)a1 << 32) | a0;
+            vwin = sh ? ((lo >> sh) | ((uint64_t)a2 << (64 - sh))) : lo;
+        }
+        uint32_t m = (uint32_t)msyms, mused = 0;         /* next MEL symbols, LSB first */
+        uint32_t a = (uint32_t)vwin, aused = 0;         /* the two codewords need <= 14 bits */
+        int rho[2], uoff[2], ek[2], e1[2];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const bool en = k == 0 || pair;
-                const int q = qx + k;
-                const int ra = ra_next;
-                const int rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
-                const int ctx = row0 ? ctx_run
-                                     : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
-                                        ((((ra >> 3) | (rar >> 1)) & 1) << 2));
-                const bool mq = en && ctx == 0;
-                const int msym = (int)(m & 1);
-                m >>= mq ? 1 : 0; mused += mq ? 1 : 0;
-                const bool dec = en && (ctx != 0 || msym != 0);
-                const uint32_t e = dec ? table[(ctx << 7) | (a & 0x7F)] : 0u;
-                const uint32_t len = (e >> 1) & 7;
-                a >>= len; aused += len;
-                uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; ek[k] = (e >> 8) & 0xF; e1[k] = (e >> 12) & 0xF;
-                if (en) {
-                    rho_left = rho[k];
-                    ral = ra;
-                    ra_next = rar;
-                    ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
-                }
+        for (int k = 0; k < 2; k++) {
+            const bool en = active && (k == 0 || pair);
+            const int q = qx + k;
+            const int ra = ra_next;
+            const int rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
+            const int ctx = row0 ? ctx_run
+                                 : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
+                                    ((((ra >> 3) | (rar >> 1)) & 1) << 2));
+            const bool mq = en && ctx == 0;
+            const int msym = (int)(m & 1);
+            m >>= mq ? 1 : 0; mused += mq ? 1 : 0;
+            const bool dec = en && (ctx != 0 || msym != 0);
+            const uint32_t e = dec ? table[(ctx << 7) | (a & 0x7F)] : 0u;
+            const uint32_t len = (e >> 1) & 7;
+            a >>= len; aused += len;
+            uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; ek[k] = (e >> 8) & 0xF; e1[k] = (e >> 12) & 0xF;
+            if (en) {
+                rho_left = rho[k];
+                ral = ra;
+                ra_next = rar;
+                ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
             }
-            /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) for both quads, branch-free, on a
-             * fresh 32-bit window (<= 24 bits): decode order pfx1 pfx2 sfx1 sfx2 ext1 ext2; first
-             * row with both offsets set: one MEL symbol, 1 => both u get +2, 0 and pfx1 > 2 => u2
-             * is a single bit + 1 */
-            uint32_t u32w = (uint32_t)(vwin >> aused), uused;
-            const bool both = uoff[0] && uoff[1];
-            const bool mq2 = row0 && both;
-            const int mel2 = (int)(m & 1);
-            mused += mq2 ? 1 : 0;
-            const int mode = (mq2 && !mel2) ? 4 : (uoff[0] | (uoff[1] << 1));
-            const uint32_t ue = utbl[(mode << 6) | (u32w & 63)];
-            const int p1 = ue & 7, p2 = (ue >> 3) & 7;
-            uint32_t d = (ue >> 6) & 7;
-            u32w >>= d; uused = d;
-            d = (ue >> 9) & 7;
-            const int s1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
-            d = (ue >> 12) & 7;
-            const int s2 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
-            d = s1 >= 28 ? 4u : 0u;
-            const int x1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
-            d = s2 >= 28 ? 4u : 0u;
-            const int x2 = (int)(u32w & ((1u << d) - 1)); uused += d;
-            const int bias = (mq2 && mel2) ? 2 : 0;
-            const int u1 = uoff[0] ? bias + p1 + s1 + 4 * x1 : 0;
-            const int u2 = uoff[1] ? bias + p2 + s2 + 4 * x2 : 0;
+        }
+        /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) for both quads, branch-free, on a
+         * fresh 32-bit window (<= 24 bits): decode order pfx1 pfx2 sfx1 sfx2 ext1 ext2; first
+         * row with both offsets set: one MEL symbol, 1 => both u get +2, 0 and pfx1 > 2 => u2
+         * is a single bit + 1 */
+        uint32_t u32w = (uint32_t)(vwin >> aused), uused;
+        const bool both = uoff[0] && uoff[1];
+        const bool mq2 = row0 && both;
+        const int mel2 = (int)(m & 1);
+        mused += mq2 ? 1 : 0;
+        const int mode = (mq2 && !mel2) ? 4 : (uoff[0] | (uoff[1] << 1));
+        const uint32_t ue = utbl[(mode << 6) | (u32w & 63)];
+        const int p1 = ue & 7, p2 = (ue >> 3) & 7;
+        uint32_t d = (ue >> 6) & 7;
+        u32w >>= d; uused = d;
+        d = (ue >> 9) & 7;
+        const int s1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+        d = (ue >> 12) & 7;
+        const int s2 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+        d = s1 >= 28 ? 4u : 0u;
+        const int x1 = (int)(u32w & ((1u << d) - 1)); u32w >>= d; uused += d;
+        d = s2 >= 28 ? 4u : 0u;
+        const int x2 = (int)(u32w & ((1u << d) - 1)); uused += d;
+        const int bias = (mq2 && mel2) ? 2 : 0;
+        const int u1 = uoff[0] ? bias + p1 + s1 + 4 * x1 : 0;
+        const int u2 = uoff[1] ? bias + p2 + s2 + 4 * x2 : 0;
+        if (active) {
             vpos += aused + uused;
             msyms >>= mused; mcnt -= (int)mused;
             myrho[qx] = (uint8_t)rho[0];
             if (pair) myrho[qx + 1] = (uint8_t)rho[1];
-            /* single wait point: next iteration's windows (loaded at the top) become current,
-             * then this pair's symbols are stored -- they have a whole iteration to drain */
-            if (!(dbg & 1)) {
-                rowout[qx] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
-                if (pair)
-                    rowout[qx + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
-            }
+        }
+        ost[2 * (t & 7)] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
+        ost[2 * (t & 7) + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
+        /* next quad pair of this lane's block */
+        qx += 2;
+        if (active && qx >= qw) {
+            qx = 0; row++;
+            rho_left = 0; ral = 0;
+            ra_next = (int)myrho[0];                     /* above quad 0 of the new row */
         }
     }
+    if (max_it > 0) flush((max_it - 1) >> 3);
 }
 
 }  // namespace htj2k

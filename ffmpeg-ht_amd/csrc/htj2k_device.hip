@@ -793,7 +793,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         for (size_t i = 0; i < j->blocks.size(); i++) {
             j->qoff[i] = (uint32_t)q;
             const J2kBlock &b = j->blocks[i];
-            if (b.npasses) q += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
+            if (b.npasses) q += ht_qsym_words(b.w, b.h);
         }
         if (q > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
         j->nquads = q;
@@ -996,7 +996,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
         if (nblocks) {
             HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
-            const size_t vlc_lds = 4096 + 1024 + HT_VSTAGE_BYTES + (size_t)((((j->max_qw + 3) >> 2) | 1) << 2) * 64;
+            const size_t vlc_lds = ht_vlc_lds_bytes(j->max_qw);
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
@@ -1012,7 +1012,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
-                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, 0);
+                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads + 32);
                 if (!j->reflist.empty())
                     hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, (const uint32_t *)j->d_reflist.p, (int)j->reflist.size(),
@@ -1454,7 +1454,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     for (int i = 0; i < nblocks; i++) {
         const J2kBlock &b = ((const J2kBlock *)blocks)[i];
         qoff[i] = (uint32_t)nq;
-        if (b.npasses) nq += (size_t)((b.w + 1) >> 1) * ((b.h + 1) >> 1);
+        if (b.npasses) nq += ht_qsym_words(b.w, b.h);
     }
     /* blocks with refinement passes that k_ht_refine handles (same rule as htj2k_job_upload) */
     std::vector<uint32_t> reflist, roff(nblocks + 1, 0);
@@ -1491,7 +1491,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     if (e == hipSuccess) e = hipMemcpy(dqo.p, qoff.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dro.p, roff.data(), roff.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && !reflist.empty()) e = hipMemcpy(drl.p, reflist.data(), reflist.size() * 4, hipMemcpyHostToDevice);
-    const size_t vlc_lds = 4096 + 1024 + HT_VSTAGE_BYTES + (size_t)((((tmp.lds.max_qw + 3) >> 2) | 1) << 2) * 64;
+    const size_t vlc_lds = ht_vlc_lds_bytes(tmp.lds.max_qw);
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
@@ -1506,7 +1506,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
             hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
-                               tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, 0);
+                               tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq + 32);
             if (!reflist.empty())
                 hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
                                    (const J2kBlock *)db.p, (const uint32_t *)drl.p, (int)reflist.size(), (const uint8_t *)dby.p,
