@@ -257,6 +257,10 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
     const int q = col >> 1, sh = (col & 1) * 2;
     const int dshift = 31 - M_b;
     const uint32_t half = 1u << ((pLSB - 1) & 31);
+    /* 5/3 shortcut (block-uniform): valid when the magnitude LSB sits at or above the dequantiser's (always, in a
+     * conforming stream) and at least one magnitude bit survives the 31-bit mask */
+    const bool direct53 = pLSB >= dshift && pLSB >= 1 && pLSB <= 30;
+    const uint32_t keep53 = (uint32_t)(31 - pLSB) & 31u, up53 = (uint32_t)(pLSB - dshift) & 31u, hb53 = (half & 0x7FFFFFFFu) >> (dshift & 31);
     uint32_t ms_pos = 0, Eb = 0;
     int err = 0;
     const int qwp = (int)ht_qsym_pitch((uint32_t)w);       /* k_ht_vlc pads the symbol rows to an even quad count */
@@ -284,7 +288,9 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
         }
         const int U = kappa + (int)uq;
         if (act && U > maxbp) err = 1;
-        const int m_t = (s_t ? U : 0) - (int)k_t, m_b = (s_b ? U : 0) - (int)k_b;
+        /* m = s * U - k as one 24-bit multiply-add; k is only ever set where s is (the CxtVLC tables'
+         * e_k is a subset of rho), so m >= 0 */
+        const int m_t = __mul24((int)s_t, U) - (int)k_t, m_b = __mul24((int)s_b, U) - (int)k_b;
         const uint32_t nt = (uint32_t)max(m_t, 0), nb = (uint32_t)max(m_b, 0);
         const uint32_t incl = wave_incl_scan_u32(nt + nb, lane);
         const uint32_t pos = ms_pos + incl - nt - nb;
@@ -297,14 +303,17 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
         const uint32_t sb = bs + nt;                       /* 0 .. 62 */
         const bool hiw = sb >= 32;
         uint32_t vb = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hiw ? w2 : w1, hiw ? w1 : w0, sb), 0u, nb);
-        /* a negative m (e_k outside rho: not in the Annex C tables) reads no bits and has v = 0 */
-        vt = m_t > 0 ? vt + (e_t << nt) : 0u;
-        vb = m_b > 0 ? vb + (e_b << nb) : 0u;
-        uint32_t mu_t = ((((vt >> 1) + 1) << pLSB) | half) | (vt << 31);
-        uint32_t mu_b = ((((vb >> 1) + 1) << pLSB) | half) | (vb << 31);
-        mu_t = m_t != 0 ? mu_t : 0u;
-        mu_b = m_b != 0 ? mu_b : 0u;
+        /* m == 0: no bits were read and the sample is zero whatever e_1 says (:395-427) */
+        vt += e_t << nt;
+        vb += e_b << nb;
         Eb = m_b != 0 ? (uint32_t)(32 - __clz((int)(vb | 1))) : 0u;
+        uint32_t mu_t = 0, mu_b = 0;
+        if (REFINE || TRANSFORM != J2K_DWT53 || !direct53) {
+            mu_t = ((((vt >> 1) + 1) << pLSB) | half) | (vt << 31);
+            mu_b = ((((vb >> 1) + 1) << pLSB) | half) | (vb << 31);
+            mu_t = m_t != 0 ? mu_t : 0u;
+            mu_b = m_b != 0 ? mu_b : 0u;
+        }
         const bool two = 2 * row + 1 < h;                  /* odd heights: the outside half of the last quad row is discarded (:976-1007) */
         if (REFINE) {
             /* the SigProp / MagRef decisions of k_ht_refine, three 64-bit masks per sample row (newly
@@ -328,10 +337,23 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
         } else {
             uint32_t o_t, o_b;
             if (TRANSFORM == J2K_DWT53) {
-                const int sg_t = (int)mu_t >> 31, sg_b = (int)mu_b >> 31;
-                int r_t = (int)((mu_t & 0x7FFFFFFFu) >> dshift), r_b = (int)((mu_b & 0x7FFFFFFFu) >> dshift);
-                r_t = (r_t ^ sg_t) - sg_t;
-                r_b = (r_b ^ sg_b) - sg_b;
+                int r_t, r_b;
+                if (direct53) {
+                    /* ((((v >> 1) + 1) << pLSB | half) & 0x7FFFFFFF) >> dshift without building mu: the
+                     * magnitude keeps its low 31 - pLSB bits and moves up by pLSB - dshift >= 0 */
+                    const int sg_t = -(int)(vt & 1), sg_b = -(int)(vb & 1);
+                    r_t = (int)((__builtin_amdgcn_ubfe((vt >> 1) + 1, 0u, keep53) << up53) | hb53);
+                    r_b = (int)((__builtin_amdgcn_ubfe((vb >> 1) + 1, 0u, keep53) << up53) | hb53);
+                    r_t = (r_t ^ sg_t) - sg_t;
+                    r_b = (r_b ^ sg_b) - sg_b;
+                    r_t = m_t != 0 ? r_t : 0;
+                    r_b = m_b != 0 ? r_b : 0;
+                } else {
+                    const int sg_t = (int)mu_t >> 31, sg_b = (int)mu_b >> 31;
+                    r_t = (int)((mu_t & 0x7FFFFFFFu) >> dshift); r_b = (int)((mu_b & 0x7FFFFFFFu) >> dshift);
+                    r_t = (r_t ^ sg_t) - sg_t;
+                    r_b = (r_b ^ sg_b) - sg_b;
+                }
                 if (i_step != 32768) {                      /* wave-uniform; reversible bands have step 1.0 */
                     const long long a = (long long)r_t * i_step, b2 = (long long)r_b * i_step;
                     r_t = (int)(a < 0 ? -((-a) >> 16) : (a >> 16));
