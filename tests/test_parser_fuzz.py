@@ -1,0 +1,42 @@
+"""The host parser takes untrusted input (jpeg2000dec.c's job in the reference): mutated codestreams under
+AddressSanitizer + UBSan must neither crash nor read outside the packet, and every plan it accepts must be
+self-consistent (CPU only; sanitizers are not available for the GPU build)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import streams
+import vecgen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_parser_survives_mutations_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "fuzz_parse"
+    cmd = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ffmpeg-ht_amd", "csrc"),
+           "-o", str(exe), os.path.join(HERE, "native", "fuzz_parse.c"),
+           os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_parse.c"), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = []
+    for name in ["gray_l5_cb64", "rgb_mct", "rgb_tiles_offsets", "rgb_cprl_prec", "gray_sop_eph", "yuv420p8",
+                 "gray_3passes", "placeholder_2_3p", "tiny_3x1_l2", "psot_zero"]:
+        f = tmp_path / (name + ".j2c")
+        f.write_bytes(streams.get(name)[0])
+        files.append(str(f))
+    img = streams._img(96, 64, 3, 10, 21)
+    jp2 = tmp_path / "wrapped.jp2"
+    jp2.write_bytes(vecgen.jp2_wrap(vecgen.encode(img, depth=10, nlevels=3), 96, 64, 3, 10, colourspace=18,
+                                    res=(300, 1, 150, 1, 0, 0)))
+    files.append(str(jp2))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([str(exe), "120"] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "fuzz:" in r.stdout
