@@ -824,7 +824,9 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_qsym.ensure((j->nquads + 64) * sizeof(uint32_t))) < 0) return r;
     if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
-    if ((r = j->d_vlcu.ensure(j->nbytes + 256)) < 0 || (r = j->d_melu.ensure(j->nbytes + 256)) < 0) return r;
+    /* a corrupt block can run k_ht_vlc's bit positions past its own arrays (38 VLC / 18 MEL bits per quad pair at
+     * most, 4096 samples per block: < 3 KB): the last block of the pool must still read inside the allocation */
+    if ((r = j->d_vlcu.ensure(j->nbytes + 16384)) < 0 || (r = j->d_melu.ensure(j->nbytes + 16384)) < 0) return r;
     if ((r = j->d_reflist.ensure((j->reflist.size() + 1) * sizeof(uint32_t))) < 0 ||
         (r = j->d_roff.ensure(j->roff.size() * sizeof(uint32_t))) < 0 ||
         (r = j->d_refbits.ensure((j->nrefmasks + 8) * sizeof(uint64_t))) < 0) return r;
@@ -1476,7 +1478,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         drl.release(); dro.release(); drb.release();
     };
     if ((r = dq.ensure((nq + 64) * 4)) < 0 || (r = dqo.ensure((size_t)(nblocks + 1) * 4)) < 0 ||
-        (r = du[0].ensure(nbytes + 256)) < 0 || (r = du[1].ensure(nbytes + 256)) < 0 ||
+        (r = du[0].ensure(nbytes + 16384)) < 0 || (r = du[1].ensure(nbytes + 16384)) < 0 ||
         (r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(nbytes + 64)) < 0 ||
         (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0 ||
         (r = drl.ensure((reflist.size() + 1) * 4)) < 0 || (r = dro.ensure(roff.size() * 4)) < 0 ||
