@@ -236,7 +236,7 @@ def main():
         achieved_hbm = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
         traffic = committed_traffic(args.batch) if njobs == 1 else None
         res = {
-            "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3)",
+            "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3) at 1/2/4/8 GPU; IDWT HBM GB/s vs peak",
             "value": round(value, 2),
             "unit": "Mpixel/s",
             "n_gpus": world,
