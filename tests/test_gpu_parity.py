@@ -387,3 +387,35 @@ def test_full_size_8k_16bit(dec, orc):
     info, planes, _, st = dec.decode(data)
     assert st.n_codeblocks == 8227 and st.n_block_errors == 0
     assert np.array_equal(planes[0], img[0])
+
+
+def test_full_size_4k_10bit_stream_sharded(dec, orc):
+    """BASELINE config 5 in miniature: a stream of 4K 10-bit lossless RGB frames (rgb48, samples << 6), distinct
+    seeds, sharded round-robin over ranks (bench.shard_frames) -- here every "rank" is the same GPU -- each rank's
+    frames going through the pipeline; lossless round trip and a checksum against the oracle for one frame."""
+    import bench
+    nframes, world = 6, 2
+    imgs = [vecgen.synth_image(3840, 2160, 3, depth=10, seed=50 + i, noise=20) for i in range(nframes)]
+    pkts = [vecgen.encode(im, depth=10, mct=1) for im in imgs]
+    seen = set()
+    for rank in range(world):
+        mine = bench.shard_frames(nframes, rank, world)
+        pipe = dec.pipe(batch=2, depth=2)
+        try:
+            out, sent = [], 0
+            while len(out) < len(mine):
+                while sent < len(mine) and pipe.send(pkts[mine[sent]]):
+                    sent += 1
+                if sent == len(mine):
+                    pipe.flush()
+                out.append(pipe.receive())
+        finally:
+            pipe.close()
+        for f, (info, planes) in zip(mine, out):
+            seen.add(f)
+            got = planes[0].reshape(2160, 3840, 3).astype(np.int64) >> 6       # write_frame_16: << (16 - 10)
+            assert np.array_equal(got, np.stack(imgs[f], -1)), f
+            if f == 1:
+                _, planes_o, _ = orc.decode(pkts[f])
+                assert oracle.framecrc(planes) == oracle.framecrc(planes_o)
+    assert seen == set(range(nframes))
