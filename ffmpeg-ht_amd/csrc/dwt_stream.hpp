@@ -160,8 +160,14 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 
     /* ---- rows of this strip ---- */
     const int a_first = g.mv + y0, a_last = g.mv + min(y0 + th, g.lv) - 1;
-    const int s_first = (a_first - HALO) & ~1;
-    const int s_last = (a_last + DELAY + 1) & ~1;
+    /* Odd strips walk UP their rows, even strips down.  The lifting is symmetric, so the upward walk is
+     * the same recurrence with the high row of a step taken below instead of above its low row.  Two
+     * vertically adjacent strips -- which start together: consecutive strip numbers on one XCD -- then
+     * read the HALO rows they share at the same moment (both at their start, or both at their end)
+     * and the second reader hits in L2 instead of fetching them again. */
+    const int dir = (by & 1) ? -1 : 1;
+    const int s_first = dir > 0 ? (a_first - HALO) & ~1 : (a_last + HALO + 1) & ~1;
+    const int s_last = dir > 0 ? (a_last + DELAY + 1) & ~1 : (a_first - DELAY) & ~1;
 
     /* The loads of a step: unconditional and the same number on every pass of the loop, so
      * that the compiler can wait for exactly the older step's loads (s_waitcnt vmcnt(N)) while
@@ -170,7 +176,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         int iy[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int ay = min(ye, s_last) + r;             /* the one prefetch past the strip re-reads its last rows */
+            const int ay = (dir > 0 ? min(ye, s_last) : max(ye, s_last)) + r * dir;   /* the one prefetch past the strip re-reads its last rows */
             iy[r] = (ay >= LY.i0 && ay < LY.i1) ? ((ay & 1) ? LY.nl + ((ay - LY.fo) >> 1) : ((ay - LY.fe) >> 1)) : LY.idx(ay);
         }
         /* even absolute rows are vertical-low rows (the reflection keeps the parity): their
@@ -366,8 +372,8 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 }
             }
         }
-        emit(ye - DELAY - 1, r_odd, 0);
-        emit(ye - DELAY, r_even, 1);
+        emit(ye - dir * (DELAY + 1), r_odd, 0);
+        emit(ye - dir * DELAY, r_even, 1);
     };
 
     /* two register buffers, loop unrolled by two: the loads of step s + 1 are in flight while
@@ -390,15 +396,15 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
             asm volatile("" : : "v"(wk[0][0]), "v"(wk[0][1]), "v"(wk[0][2]), "v"(wk[1][0]), "v"(wk[1][1]), "v"(wk[1][2]),
                                 "v"(ak[0]), "v"(ak[1]));
     };
-    for (int ye = s_first;; ye += 4) {
-        load_rows(ye + 2, LB, HB);
+    for (int ye = s_first;; ye += 4 * dir) {
+        load_rows(ye + 2 * dir, LB, HB);
         pin(LA, HA);
         step(ye, LA, HA);
-        if (ye + 2 > s_last) break;
-        load_rows(ye + 4, LA, HA);
+        if (dir * (ye + 2 * dir - s_last) > 0) break;
+        load_rows(ye + 4 * dir, LA, HA);
         pin(LB, HB);
-        step(ye + 2, LB, HB);
-        if (ye + 4 > s_last) break;
+        step(ye + 2 * dir, LB, HB);
+        if (dir * (ye + 4 * dir - s_last) > 0) break;
     }
 }
 
