@@ -203,7 +203,7 @@ def main():
 
     # the asynchronous pipeline (htj2k_pipe_*): packets in host memory -> frames in host memory, with host
     # parsing (several threads), H2D, kernels and D2H of different batches overlapping
-    pipe_rate = pipe_rate_pinned = 0.0
+    pipe_rate = pipe_rate_pinned = pipe_rate_device = 0.0
     if not args.no_e2e:
         info0 = dec.probe(streams[0])
         pk = [m.packet(x) for x in streams]
@@ -225,6 +225,24 @@ def main():
             rate = (got - nwarm) * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6 if t0 and got > nwarm else 0.0
             pipe.close()
             return rate
+        def run_pipe_device(nwarm=24, nfr=192):
+            pipe = dec.pipe(batch=8, depth=3)
+            sent = got = 0
+            t0 = None
+            while got < nwarm + nfr:
+                while sent < nwarm + nfr and pipe.send(pk[sent % len(pk)]):
+                    sent += 1
+                if sent == nwarm + nfr:
+                    pipe.flush()
+                if pipe.receive_device() is None:
+                    break
+                got += 1
+                if got == nwarm:
+                    t0 = time.perf_counter()
+            rate = (got - nwarm) * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6 if t0 and got > nwarm else 0.0
+            pipe.close()
+            return rate
+        pipe_rate_device = run_pipe_device()
         pipe_rate = run_pipe(m.alloc_frame(info0))
         pinned, ptrs = dec.alloc_frame_pinned(info0)
         pipe_rate_pinned = run_pipe(pinned)
@@ -274,6 +292,7 @@ def main():
                      "end_to_end_Mpixel_s_single_frame_calls": round(e2e, 1),
                      "end_to_end_Mpixel_s_pipeline": round(pipe_rate, 1),
                      "end_to_end_Mpixel_s_pipeline_pinned_frames": round(pipe_rate_pinned, 1),
+                     "packets_to_device_frames_Mpixel_s_pipeline": round(pipe_rate_device, 1),
                      "pipeline": "htj2k_pipe: 96 frames after 24 warm-up, batches of 8, 3 in flight, pageable packets in, "
                                  "frames out into pageable / page-locked (htj2k_host_alloc) planes"},
         }

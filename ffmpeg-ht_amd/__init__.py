@@ -78,7 +78,8 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
-           "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free"]
+           "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
+           "htj2k_pipe_receive_device", "htj2k_job_device_frame"]
 
 _lib = None
 
@@ -284,6 +285,15 @@ class Pipe:
         planes, fr = into if into is not None else alloc_frame(info)
         _check(self.dec.L.htj2k_pipe_receive(self.h, ctypes.byref(fr)), "htj2k_pipe_receive")
         return info, planes_to_arrays(info, planes)
+
+    def receive_device(self):
+        """-> Frame whose data[] are device pointers (no copy), None when nothing is in flight"""
+        fr = Frame()
+        r = self.dec.L.htj2k_pipe_receive_device(self.h, ctypes.byref(fr))
+        if r == EAGAIN:
+            return None
+        _check(r, "htj2k_pipe_receive_device")
+        return fr
 
     def close(self):
         if self.h:

@@ -1181,6 +1181,24 @@ extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame
     return htj2k_job_download_frame(c, j, 0, frame);
 }
 
+/* device addresses / pitches of the output planes of frame f (for callers that keep frames on the GPU); valid
+ * until the job is parsed again */
+extern "C" int htj2k_job_device_frame(htj2k_ctx *c, htj2k_job *j, int f, htj2k_frame *frame)
+{
+    if (!c || !j || f < 0 || f >= j->nframes || !frame) return HTJ2K_ERR_EINVAL;
+    const FrameSlot &F = j->frames[f];
+    const J2kPlan *pl = F.plan;
+    memset(frame, 0, sizeof(*frame));
+    for (int p = 0; p < pl->info.nplanes; p++) {
+        frame->data[p] = F.out.ptr[p];
+        frame->linesize[p] = F.out.linesize[p];
+    }
+    frame->width = pl->info.width;
+    frame->height = pl->info.height;
+    frame->pix_fmt = pl->info.pix_fmt;
+    return 0;
+}
+
 /* device address of an output plane of frame 0 (for callers that keep frames on the GPU) */
 extern "C" void *htj2k_job_device_plane(htj2k_job *j, int plane, int *linesize)
 {

@@ -219,6 +219,29 @@ extern "C" int htj2k_pipe_receive(htj2k_pipe *p, htj2k_frame *frame)
     return r;
 }
 
+extern "C" int htj2k_pipe_receive_device(htj2k_pipe *p, htj2k_frame *frame)
+{
+    if (!p || !frame) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot *s = nullptr;
+    int r = due_slot(p, lk, &s);
+    if (r < 0) return r;
+    lk.unlock();
+    if (s->rc >= 0) {
+        r = htj2k_job_device_frame(p->ctx, s->job, s->next_out, frame);
+    } else {                                               /* failed batch: this packet alone */
+        const Packet &pk = s->pkts[s->next_out];
+        r = htj2k_job_parse(p->ctx, pk.data, pk.size, &p->single);
+        if (r >= 0) r = htj2k_job_upload(p->ctx, p->single);
+        if (r >= 0) r = htj2k_job_run(p->ctx, p->single);
+        if (r >= 0) r = htj2k_job_wait(p->ctx, p->single);
+        if (r >= 0) r = htj2k_job_device_frame(p->ctx, p->single, 0, frame);
+    }
+    lk.lock();
+    pop_frame(p, *s);
+    return r;
+}
+
 /* drop the next frame without copying it out (e.g. after htj2k_pipe_info reported an error) */
 extern "C" int htj2k_pipe_skip(htj2k_pipe *p)
 {

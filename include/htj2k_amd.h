@@ -191,6 +191,9 @@ int  htj2k_ht_blocks(htj2k_ctx *ctx, const void *blocks, int nblocks, const uint
 /* codeblocks the HT decoder rejected in the job's last run (they are left zero) */
 int  htj2k_job_block_errors(htj2k_ctx *ctx, htj2k_job *job);
 int  htj2k_job_num_blocks(const htj2k_job *job);
+/* device addresses of the decoded planes of frame `frame` of the job (data[] = device pointers), for callers that
+ * keep frames on the GPU; valid until the job is parsed again */
+int  htj2k_job_device_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
 /* device address of an output plane, for callers that keep decoded frames on the GPU */
 void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
 /* tuning / test knobs:
@@ -232,6 +235,9 @@ int  htj2k_pipe_send_ref(htj2k_pipe *pipe, const uint8_t *pkt, int size, void (*
 int  htj2k_pipe_flush(htj2k_pipe *pipe);
 int  htj2k_pipe_info(htj2k_pipe *pipe, htj2k_info *info);
 int  htj2k_pipe_receive(htj2k_pipe *pipe, htj2k_frame *out);
+/* as htj2k_pipe_receive without the copy: `out->data[]` are the device pointers of the decoded planes; they stay
+ * valid until the pipe has handed out the frames of `depth - 1` further batches (the job is then reused) */
+int  htj2k_pipe_receive_device(htj2k_pipe *pipe, htj2k_frame *out);
 int  htj2k_pipe_skip(htj2k_pipe *pipe);
 void htj2k_pipe_close(htj2k_pipe *pipe);
 

@@ -124,6 +124,11 @@ def test_batch_job_of_mixed_frames(dec, orc, fuse):
             assert any(hb < by for (ms, by), hb in zip(launches, hbm))
         else:
             assert all(hb == by for (ms, by), hb in zip(launches, hbm))
+        import ffmpeg_ht_amd as m
+        fr0 = m.Frame()
+        assert dec.L.htj2k_job_device_frame(dec.h, job.h, 0, ctypes.byref(fr0)) == 0
+        ls = ctypes.c_int(0)
+        assert fr0.data[0] == dec.L.htj2k_job_device_plane(job.h, 0, ctypes.byref(ls)) and fr0.linesize[0] == ls.value
         for f, name in enumerate(names):
             info_o, planes_o, _ = orc.decode(pkts[f])
             info, planes = job.download_frame(f)
