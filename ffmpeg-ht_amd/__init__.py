@@ -372,6 +372,11 @@ class Decoder:
         r = _check(self.L.htj2k_decode(self.h, self._buf, len(data), ctypes.byref(fr), ctypes.byref(st)), "htj2k_decode")
         return info, planes_to_arrays(info, planes), r, st
 
+    def decode_into(self, pkt, buf):
+        """htj2k_decode of a packet() into the planes of alloc_frame(): nothing is copied or allocated in Python"""
+        st = Stats()
+        return _check(self.L.htj2k_decode(self.h, pkt[0], pkt[1], ctypes.byref(buf[1]), ctypes.byref(st)), "htj2k_decode"), st
+
     def job(self):
         return Job(self)
 
