@@ -14,6 +14,10 @@ all: lib oracle vecgen
 lib: $(PKG)/libhtj2k_amd.so
 oracle: oracle/libj2k_oracle.so
 vecgen: tools/vecgen/libhtj2k_vecgen.so
+ubench: tools/ubench/membw
+
+tools/ubench/membw: tools/ubench/membw.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
 $(CSRC)/j2k_parse.o: $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h include/htj2k_amd.h
 	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@

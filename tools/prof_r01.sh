@@ -6,6 +6,7 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r01
 mkdir -p $O
+[ -x $R/tools/ubench/membw ] || make -C $R ubench > /dev/null 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $BENCH > $O/bench_trace.log 2>&1 || exit 1
