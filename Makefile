@@ -15,6 +15,10 @@ lib: $(PKG)/libhtj2k_amd.so
 oracle: oracle/libj2k_oracle.so
 vecgen: tools/vecgen/libhtj2k_vecgen.so
 ubench: tools/ubench/membw
+examples: examples/htj2k_decode
+
+examples/htj2k_decode: examples/htj2k_decode.c include/htj2k_amd.h $(PKG)/libhtj2k_amd.so
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude -o $@ $< -L$(PKG) -lhtj2k_amd -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 tools/ubench/membw: tools/ubench/membw.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
@@ -45,4 +49,4 @@ tools/vecgen/libhtj2k_vecgen.so: tools/vecgen/htj2k_enc.c tools/vecgen/htj2k_enc
 clean:
 	rm -f $(CSRC)/*.o $(PKG)/*.so oracle/*.so tools/vecgen/*.so
 
-.PHONY: all lib oracle vecgen clean
+.PHONY: all lib oracle vecgen ubench examples clean

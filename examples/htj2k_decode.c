@@ -1,0 +1,109 @@
+/*
+ * htj2k_decode.c -- the C ABI of include/htj2k_amd.h used from plain C, the way an FFmpeg-side glue would
+ * (INTEGRATION.md): open, probe, allocate planes, decode, close.
+ *
+ *   htj2k_decode in.j2c [out.raw]            one codestream / JP2 file -> raw planes (plane after plane, tight rows)
+ *   htj2k_decode -p N in.j2c [out.raw]       the same packet N times through the asynchronous pipeline
+ *                                            (htj2k_pipe_*), frames written are those of the last round
+ *
+ * build: make examples   (cc examples/htj2k_decode.c -Iinclude -Lffmpeg-ht_amd -lhtj2k_amd)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "htj2k_amd.h"
+
+static void log_cb(void *opaque, int level, const char *msg)
+{
+    (void)opaque;
+    fprintf(stderr, "[htj2k %d] %s", level, msg);
+}
+
+static double now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + t.tv_nsec * 1e-9;
+}
+
+static int alloc_planes(const htj2k_info *info, htj2k_frame *fr)
+{
+    memset(fr, 0, sizeof(*fr));
+    for (int p = 0; p < info->nplanes; p++) {
+        fr->linesize[p] = info->plane_width[p] * info->plane_bytes_per_sample[p];
+        fr->data[p] = malloc((size_t)fr->linesize[p] * info->plane_height[p]);
+        if (!fr->data[p]) return -1;
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int npipe = 0, a = 1;
+    if (argc > 2 && !strcmp(argv[1], "-p")) { npipe = atoi(argv[2]); a = 3; }
+    if (argc <= a) { fprintf(stderr, "usage: %s [-p N] in.j2c [out.raw]\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[a], "rb");
+    if (!f) { perror(argv[a]); return 2; }
+    fseek(f, 0, SEEK_END);
+    long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *pkt = calloc(1, (size_t)size + 64);                 /* AV_INPUT_BUFFER_PADDING_SIZE */
+    if (!pkt || fread(pkt, 1, (size_t)size, f) != (size_t)size) { fprintf(stderr, "read error\n"); return 2; }
+    fclose(f);
+
+    htj2k_opts opts;
+    memset(&opts, 0, sizeof(opts));
+    opts.req_pix_fmt = HTJ2K_PIX_NONE;
+    htj2k_ctx *ctx = NULL;
+    int r = htj2k_open(&opts, &ctx);
+    if (r < 0) { fprintf(stderr, "htj2k_open: %d (no gfx950 device? there is no CPU fallback)\n", r); return 1; }
+    htj2k_set_log(ctx, log_cb, NULL);
+
+    htj2k_info info;
+    if ((r = htj2k_probe(ctx, pkt, (int)size, &info)) < 0) { fprintf(stderr, "htj2k_probe: %d\n", r); return 1; }
+    htj2k_frame fr;
+    if (alloc_planes(&info, &fr) < 0) return 1;
+    printf("%s: %dx%d pix_fmt %d, %d bits, %d component(s), %s, HT %d, device %s\n", argv[a], info.width, info.height,
+           info.pix_fmt, info.bits_per_raw_sample, info.ncomponents, info.lossless ? "lossless" : "lossy", info.is_ht,
+           htj2k_device_name(ctx));
+
+    if (!npipe) {
+        htj2k_stats st;
+        memset(&st, 0, sizeof(st));
+        double t0 = now();
+        r = htj2k_decode(ctx, pkt, (int)size, &fr, &st);
+        double t1 = now();
+        if (r < 0) { fprintf(stderr, "htj2k_decode: %d\n", r); return 1; }
+        printf("decoded %d bytes in %.2f ms: %d codeblocks (%d rejected), parse %.2f ms, device HT %.3f + IDWT %.3f + pack %.3f ms\n",
+               r, (t1 - t0) * 1e3, st.n_codeblocks, st.n_block_errors, st.ms_parse, st.ms_ht, st.ms_idwt, st.ms_pack);
+    } else {
+        htj2k_pipe *pipe = NULL;
+        if ((r = htj2k_pipe_open(ctx, 8, 3, &pipe)) < 0) { fprintf(stderr, "htj2k_pipe_open: %d\n", r); return 1; }
+        int sent = 0, got = 0;
+        double t0 = now();
+        while (got < npipe) {
+            while (sent < npipe && (r = htj2k_pipe_send_ref(pipe, pkt, (int)size, NULL, NULL)) == 0) sent++;
+            if (r < 0 && r != HTJ2K_ERR_EAGAIN) { fprintf(stderr, "htj2k_pipe_send_ref: %d\n", r); return 1; }
+            if (sent == npipe) htj2k_pipe_flush(pipe);
+            if ((r = htj2k_pipe_receive(pipe, &fr)) < 0) { fprintf(stderr, "htj2k_pipe_receive: %d\n", r); return 1; }
+            got++;
+        }
+        double t1 = now();
+        printf("pipeline: %d frames in %.1f ms = %.1f Mpixel/s\n", got, (t1 - t0) * 1e3,
+               (double)got * info.width * info.height / (t1 - t0) / 1e6);
+        htj2k_pipe_close(pipe);
+    }
+    if (argc > a + 1) {
+        FILE *o = fopen(argv[a + 1], "wb");
+        if (!o) { perror(argv[a + 1]); return 2; }
+        for (int p = 0; p < info.nplanes; p++)
+            fwrite(fr.data[p], 1, (size_t)fr.linesize[p] * info.plane_height[p], o);
+        fclose(o);
+    }
+    for (int p = 0; p < 4; p++) free(fr.data[p]);
+    free(pkt);
+    htj2k_close(ctx);
+    return 0;
+}

@@ -424,3 +424,23 @@ def test_full_size_4k_10bit_stream_sharded(dec, orc):
                 _, planes_o, _ = orc.decode(pkts[f])
                 assert oracle.framecrc(planes) == oracle.framecrc(planes_o)
     assert seen == set(range(nframes))
+
+
+def test_c_example_program(orc, tmp_path):
+    """examples/htj2k_decode.c: the C ABI driven from plain C (no Python in the loop), one-shot and pipelined"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["make", "-C", root, "examples"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = os.path.join(root, "examples", "htj2k_decode")
+    for name in ("rgb_mct", "yuv422p12_97", "gray_3passes"):
+        data, kw = streams.get(name)
+        src = tmp_path / (name + ".j2c")
+        src.write_bytes(data)
+        _, planes_o, _ = orc.decode(data, **kw)
+        want = b"".join(np.ascontiguousarray(p).tobytes() for p in planes_o)
+        for extra in ([], ["-p", "20"]):
+            out = tmp_path / (name + ".raw")
+            r = subprocess.run([exe] + extra + [str(src), str(out)], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (r.stdout, r.stderr)
+            assert out.read_bytes() == want, (name, extra)
