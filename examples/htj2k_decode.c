@@ -18,7 +18,8 @@
 static void log_cb(void *opaque, int level, const char *msg)
 {
     (void)opaque;
-    fprintf(stderr, "[htj2k %d] %s", level, msg);
+    if (level <= 24)                                     /* AV_LOG_WARNING and worse */
+        fprintf(stderr, "[htj2k %d] %s", level, msg);
 }
 
 static double now(void)
