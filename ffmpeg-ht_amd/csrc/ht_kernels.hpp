@@ -1,26 +1,30 @@
 /*
- * ht_kernels.hpp -- HT block decoder for gfx950: one 64-lane wavefront per codeblock.
+ * ht_kernels.hpp -- HT block decoder for gfx950.
  *
  * What it computes is ff_jpeg2000_decode_htj2k() (libavcodec/jpeg2000htdec.c:1188-1336)
  * followed by dequantization_int / _float / _int_97 (libavcodec/jpeg2000dec.c:2098-2181)
  * written straight into the tile-component plane at the block's Mallat position
  * (jpeg2000dec.c:2279-2287).  How it computes it is not the reference's byte-at-a-time
- * bit buffers:
+ * bit buffers.  The work of a block splits by its dependence structure:
  *
- *   stage 0 (64 lanes)  the three byte streams of the cleanup segment are un-stuffed in
- *                       parallel into LDS bit arrays: per-byte bit counts (7 after a 0xFF
- *                       for MagSgn, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
- *                       >0x8F byte for VLC, :145-201), wave prefix sum -> bit offset of
- *                       every byte, ds_or into 32-bit words.
- *   stage 1 (lane 0)    MEL + CxtVLC + U-VLC decode of one quad row (:632-973).  The
- *                       chain "codeword length -> next codeword position -> context" is
- *                       inherently serial; the two 1024-entry tables live in LDS.
- *   stage 2 (64 lanes)  lanes = sample columns of the quad row: exponent predictor kappa
- *                       from the row above (:855-885), m_n, wave prefix sum -> MagSgn bit
- *                       offsets, extraction from the LDS bit array, mu/E (:395-427),
- *                       dequantisation and two coalesced row stores.
- *   stage 3             SigProp (:1016-1131, serial on bitmaps) and MagRef (:1137-1185,
- *                       parallel popcount-prefix) when the block carries refinement passes.
+ *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, MEL, SigProp, MagRef bytes) and the
+ *                       head of k_ht_decode (MagSgn): four bytes per lane, per-byte bit counts
+ *                       (7 after a 0xFF, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
+ *                       >0x8F byte for the backward streams, :145-201), wave prefix sum -> bit
+ *                       offset of the lane's chunk, ds_or into 32-bit words.
+ *   serial chains (one LANE per block, 64 blocks per wave)
+ *                       k_ht_vlc: MEL + CxtVLC + U-VLC of every quad (:632-973) -- "codeword
+ *                       length -> next codeword position -> context" -- and k_ht_refine:
+ *                       SigProp / MagRef (:1016-1185) -- "which sample takes the next bit depends
+ *                       on the significance the previous bits made".  Neither parallelises
+ *                       inside a block, both do across blocks.
+ *   MagSgn (64 lanes per block)   k_ht_decode: lanes = sample columns of a quad row: exponent
+ *                       predictor kappa from the row above (:855-885), m_n, wave prefix sum ->
+ *                       MagSgn bit offsets, extraction from the LDS bit array, mu/E (:395-427),
+ *                       refinement bits, dequantisation and two coalesced row stores.
+ *
+ * k_ht_decode<false> is the first correct version (everything in one kernel, the serial stages on
+ * lane 0), kept as a fallback and A/B reference; its LDS layout is HtLds.
  */
 #pragma once
 #include <hip/hip_runtime.h>
