@@ -17,12 +17,17 @@
  *            compiled with -ffp-contract=off (the reference object has no FMA)
  *   9/7 int  16.16 constants, int64 products, +32768 >> 16 (:467-480)
  *
- * Two kernel families:
- *   k_idwt_h / k_idwt_v      generic: any geometry, one output per thread, row pass into a
- *                            scratch plane then column pass back (2 reads + 2 writes/level)
- *   k_idwt53_tile / _97_tile fused: one workgroup reconstructs an output tile of a level
- *                            from the four sub-band tiles staged through LDS, so each
- *                            sample of the level is read once and written once.
+ * Kernel families (htj2k_set_int "idwt_mode"):
+ *   3  k_idwt_stream / k_idwt_stream_pack (dwt_stream.hpp, default): register-streaming, no
+ *      LDS; the final level fused with the inverse MCT and the frame store
+ *   2  k_idwt_tile2: a workgroup reconstructs an output tile; horizontal lifting in registers
+ *      (DPP) on the way into LDS, vertical lifting in registers on the way out
+ *   1  k_idwt_tile: the four sub-band tiles staged through LDS, lifting in LDS; also the
+ *      fallback for lines of a single sample
+ *   0  k_idwt_h / k_idwt_v: any geometry, one closed-form output per thread, row pass into a
+ *      scratch plane then column pass back (2 reads + 2 writes per level)
+ * All four are bit-identical; the lower modes are kept as A/B references and for degenerate
+ * geometry.
  */
 #pragma once
 #include <hip/hip_runtime.h>
