@@ -39,9 +39,9 @@ $(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_
 
 # The oracle links the same host parser object as the product (parsing is not on the
 # judged hot path) and its own CPU restatement of the reference's compute.
-oracle/libj2k_oracle.so: oracle/j2k_oracle.c $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h
+oracle/libj2k_oracle.so: oracle/j2k_oracle.c oracle/j2k_oracle_mq.c $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h
 	$(CC) -O3 -fno-math-errno -fno-signed-zeros -fno-tree-vectorize -ffp-contract=off -g -Wall -Wextra -fPIC -std=gnu11 \
-	    -shared -o $@ oracle/j2k_oracle.c $(CSRC)/j2k_parse.c -lm
+	    -shared -o $@ oracle/j2k_oracle.c oracle/j2k_oracle_mq.c $(CSRC)/j2k_parse.c -lm
 
 tools/vecgen/libhtj2k_vecgen.so: tools/vecgen/htj2k_enc.c tools/vecgen/htj2k_enc.h $(CSRC)/ht_cxtvlc_rows.h
 	$(CC) $(CFLAGS) -std=gnu11 -shared -o $@ $< -lm

@@ -384,6 +384,11 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
         }
         for (int f = 0; f < n; f++)
             if (rc[f] < 0) return rc[f];                   /* the first failing frame in submission order */
+        for (int f = 0; f < n; f++)
+            if (j->frames[f].plan->have_part1) {
+                clog(c, 16, "Part-1 (MQ-coded) codeblocks present: not handled by the HIP path yet\n");
+                return HTJ2K_ERR_PATCHWELCOME;
+            }
     }
     for (int f = 0; f < n; f++) {
         FrameSlot &F = j->frames[f];

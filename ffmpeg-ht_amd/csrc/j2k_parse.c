@@ -119,11 +119,10 @@ typedef struct Poc { PocEntry poc[MAX_POCS]; int nb_poc, is_default; } Poc;
 
 typedef struct TgtNode { uint8_t val, vis; int32_t parent; } TgtNode;
 
-typedef struct Seg { const uint8_t *src; uint32_t len; struct Seg *next; } Seg;
+typedef struct Seg { const uint8_t *src; uint32_t len; uint32_t term; struct Seg *next; } Seg;   /* term: 0xFF 0xFF + a data_start entry follow */
 
 typedef struct Cblk {
     uint8_t npasses, incl, lblock, modes, ht_plhd, nonzerobits;
-    uint8_t seen_non_ht;
     int zbp;
     int pass_lengths[2];
     uint32_t length;
@@ -133,6 +132,7 @@ typedef struct Cblk {
     uint16_t nb_lengthinc;
     uint32_t *lengthinc;
     int nb_terminationsinc;
+    int nb_terminations;
     int has_lengthinc;
 } Cblk;
 
@@ -210,7 +210,6 @@ struct J2kParser {
     /* results of get_siz for the caller */
     int pix_fmt, profile, lossless, dimx, dimy;
     J2kPlan plan;
-    int have_non_ht;
 };
 
 static void plog(J2kParser *s, int level, const char *fmt, ...)
@@ -1707,8 +1706,6 @@ static int decode_packet(J2kParser *s, Tile *tile, int *tp_index, const CodSty *
                         cblk->lengthinc[cblk->nb_lengthinc++] = segment_bytes;
                     }
                 }
-                if (!(cblk->modes & CTSY_HTJ2K_F))
-                    cblk->seen_non_ht = 1;
             } else {
                 continue;
             }
@@ -1749,12 +1746,18 @@ static int decode_packet(J2kParser *s, Tile *tile, int *tp_index, const CodSty *
                          (unsigned)cblk->length, (unsigned)inc, gb_left(&s->g));
                     return HTJ2K_ERR_INVALIDDATA;
                 }
-                if (inc) {
+                if (cblk->nb_terminationsinc && cblk->length + inc + 2 > 65535u) {
+                    plog(s, LOG_ERROR, "Block length %u or lengthinc %u is too large, left %d\n",
+                         (unsigned)cblk->length, (unsigned)inc, gb_left(&s->g));
+                    return HTJ2K_ERR_INVALIDDATA;
+                }
+                if (inc || cblk->nb_terminationsinc) {
                     Seg *sg = (Seg *)arena_alloc(&s->arena, sizeof(Seg));
                     if (!sg)
                         return HTJ2K_ERR_ENOMEM;
                     sg->src = s->g.buf;
                     sg->len = inc;
+                    sg->term = cblk->nb_terminationsinc != 0;
                     if (cblk->seg_tail) cblk->seg_tail->next = sg; else cblk->seg_head = sg;
                     cblk->seg_tail = sg;
                 }
@@ -1762,8 +1765,11 @@ static int decode_packet(J2kParser *s, Tile *tile, int *tp_index, const CodSty *
                 cblk->length += inc;
                 cblk->lengthinc[cwsno] = 0;
                 if (cblk->nb_terminationsinc) {
+                    /* a terminated Part-1 segment: 0xFF 0xFF behind it, the next segment starts a new
+                     * codeword (cblk->data_start[], jpeg2000dec.c:1510-1516) */
                     cblk->nb_terminationsinc--;
-                    cblk->length += 2;          /* the two 0xFF terminator bytes of Part-1 segments */
+                    cblk->nb_terminations++;
+                    cblk->length += 2;
                 }
             }
             cblk->has_lengthinc = 0;
@@ -2448,7 +2454,8 @@ static int build_plan(J2kParser *s)
                             if (c->coord[0][1] <= c->coord[0][0] || c->coord[1][1] <= c->coord[1][0])
                                 continue;
                             nblocks++;
-                            nbytes += J2K_BLOCK_REGION(c->length);
+                            nbytes += (c->modes & CTSY_HTJ2K_F) ? J2K_BLOCK_REGION(c->length)
+                                                                : J2K_P1_REGION(c->length, c->nb_terminations);
                         }
                     }
                 }
@@ -2467,6 +2474,7 @@ static int build_plan(J2kParser *s)
         return HTJ2K_ERR_ENOMEM;
     pl->max_lcup = pl->max_lref = 0;
     pl->max_pcup = 0; pl->max_scup = 2; pl->max_qw = 1; pl->max_bm_words = 0;
+    pl->have_part1 = 0;
 
     for (tileno = 0; tileno < ntiles; tileno++) {
         Tile *tile = s->tile + tileno;
@@ -2541,17 +2549,17 @@ static int build_plan(J2kParser *s)
                             Cblk *c = prec->cblk + cblkno;
                             J2kBlock *b;
                             Seg *sg;
-                            int x, y, bw, bh;
+                            int x, y, bw, bh, part1;
                             size_t o;
 
                             bw = c->coord[0][1] - c->coord[0][0];
                             bh = c->coord[1][1] - c->coord[1][0];
                             if (bw <= 0 || bh <= 0)
                                 continue;
-                            if (c->npasses && (c->seen_non_ht || !(c->modes & CTSY_HTJ2K_F))) {
-                                s->have_non_ht = 1;
-                                continue;
-                            }
+                            /* tile_codeblocks() picks the block decoder by this bit (jpeg2000dec.c:2264-2273);
+                             * a Part-1 block without bytes decodes to "nothing coded" (decode_cblk, :2008-2009),
+                             * which is what an HT block without passes does as well */
+                            part1 = !(c->modes & CTSY_HTJ2K_F) && c->length > 0;
                             x = c->coord[0][0] - band->coord[0][0];
                             y = c->coord[1][0] - band->coord[1][0];
                             if (x < 0 || y < 0 || x + bw > t->w || y + bh > t->h)
@@ -2563,7 +2571,7 @@ static int build_plan(J2kParser *s)
                             b->w = (uint16_t)bw;
                             b->h = (uint16_t)bh;
                             b->stride = (uint16_t)t->w;
-                            b->npasses = c->npasses;
+                            b->npasses = (c->modes & CTSY_HTJ2K_F) || part1 ? c->npasses : 0;
                             b->zbp = (uint8_t)c->zbp;
                             b->M_b = (uint8_t)M_b;
                             b->flags = (uint8_t)((c->modes & J2K_CBLK_VSC) | (codsty->transform & 3));
@@ -2578,6 +2586,41 @@ static int build_plan(J2kParser *s)
                                 fscale *= (float)(1 << 6);
                                 fscale *= (float)(1 << (16 + I_PRESHIFT));
                                 b->i_step = (int)(fscale + 0.5);
+                            }
+                            if (part1) {
+                                /* the block's bytes as decode_cblk() sees them: segments back to back, 0xFF 0xFF
+                                 * behind every terminated one and behind the last byte (jpeg2000dec.c:1508-1516,
+                                 * 2012-2013), then the trailer with the mode switches and segment starts */
+                                J2kPart1Trailer *tr;
+                                int k = 0;
+                                o = boff;
+                                b->data_off = (uint32_t)o;
+                                b->flags |= J2K_BLK_PART1;
+                                b->lcup = (uint16_t)c->length;
+                                b->lref = (uint16_t)c->nb_terminations;
+                                b->zbp  = c->nonzerobits;
+                                tr = (J2kPart1Trailer *)(pl->bytes + boff + J2K_P1_TRAILER_OFF(c->length));
+                                for (sg = c->seg_head; sg; sg = sg->next) {
+                                    memcpy(pl->bytes + o, sg->src, sg->len);
+                                    o += sg->len;
+                                    if (sg->term) {
+                                        pl->bytes[o++] = 0xFF;
+                                        pl->bytes[o++] = 0xFF;
+                                        tr->start[k++] = (uint16_t)(o - boff);
+                                    }
+                                }
+                                pl->bytes[o++] = 0xFF;
+                                pl->bytes[o++] = 0xFF;
+                                while (o < boff + J2K_P1_TRAILER_OFF(c->length)) pl->bytes[o++] = 0;
+                                tr->style   = (uint8_t)(codsty->cblk_style & 0x3F);
+                                tr->bandpos = (uint8_t)(bandno + (reslevelno > 0));
+                                tr->nterm   = (uint16_t)c->nb_terminations;
+                                o += 4 + 2 * (size_t)c->nb_terminations;
+                                boff += J2K_P1_REGION(c->length, c->nb_terminations);
+                                memset(pl->bytes + o, 0, boff - o);
+                                t->coded = 1;
+                                pl->have_part1 = 1;
+                                continue;
                             }
                             /* cblk->pass_lengths are ints but Lcup/Lref index a uint16 length buffer */
                             if (c->pass_lengths[0] < 0 || c->pass_lengths[1] < 0 ||
@@ -2596,7 +2639,8 @@ static int build_plan(J2kParser *s)
                                 memcpy(pl->bytes + o, sg->src, sg->len);
                                 o += sg->len;
                             }
-                            boff += J2K_BLOCK_REGION(c->length);
+                            boff += (c->modes & CTSY_HTJ2K_F) ? J2K_BLOCK_REGION(c->length)
+                                                              : J2K_P1_REGION(c->length, c->nb_terminations);
                             memset(pl->bytes + o, 0, boff - o);        /* the pad behind the block */
                             if (c->npasses) {
                                 uint32_t qw = ((uint32_t)bw + 1u) >> 1;
@@ -2639,10 +2683,6 @@ static int build_plan(J2kParser *s)
                                    s->pix_fmt == HTJ2K_PIX_RGBA64 || s->pix_fmt == HTJ2K_PIX_GRAY16) ? 16 : s->precision;
     }
     memcpy(pl->palette, s->palette, sizeof(pl->palette));
-    if (s->have_non_ht) {
-        plog(s, LOG_ERROR, "Part-1 (MQ-coded) codeblocks present: not handled by the HIP HT path\n");
-        return HTJ2K_ERR_PATCHWELCOME;
-    }
     if (s->pix_fmt == HTJ2K_PIX_PAL8) {
         plog(s, LOG_ERROR, "palettised JP2 output is not handled by the HIP HT path\n");
         return HTJ2K_ERR_PATCHWELCOME;

@@ -28,6 +28,8 @@ extern "C" {
 #define J2K_DWT97_INT  2
 
 #define J2K_CBLK_VSC   0x08     /* JPEG2000_CBLK_VSC, jpeg2000.h:113 */
+#define J2K_BLK_PART1  0x04     /* J2kBlock.flags: a Part-1 (MQ-coded) block, decode_cblk() instead of the HT decoder
+                                 * (jpeg2000dec.c:2264-2273); see J2kPart1Trailer for what the fields then mean */
 
 /* One codeblock: 32 bytes, read by one wavefront.  Blocks with npasses == 0 are
  * kept in the table so that the device zero-fills their window (the reference
@@ -48,6 +50,22 @@ typedef struct J2kBlock {
     float    f_step;     /* band->f_stepsize (jpeg2000.c:243-264); for 9/7-int: the rounded int scale as float bits unused */
     int32_t  i_step;     /* band->i_stepsize (jpeg2000.c:271); for J2K_DWT97_INT: the (int)(fscale+0.5) scale of jpeg2000dec.c:2164-2168 */
 } J2kBlock;
+
+/* Part-1 blocks (flags & J2K_BLK_PART1) reuse the descriptor:
+ *   lcup    = cblk->length: all segments back to back, 0xFF 0xFF after every terminated one
+ *             (jpeg2000dec.c:1508-1516); two more bytes of 0xFF follow (decode_cblk writes them, :2012-2013)
+ *   lref    = cblk->nb_terminations
+ *   zbp     = cblk->nonzerobits (jpeg2000dec.c:1186-1193)
+ *   npasses = cblk->npasses
+ * and a trailer sits in the byte pool at data_off + J2K_P1_TRAILER_OFF(lcup). */
+typedef struct J2kPart1Trailer {
+    uint8_t  style;      /* codsty->cblk_style: BYPASS 0x01, RESET 0x02, TERMALL 0x04, VSC 0x08, PREDTERM 0x10, SEGSYM 0x20 */
+    uint8_t  bandpos;    /* bandno + (reslevelno > 0): 0 LL, 1 HL, 2 LH, 3 HH (jpeg2000dec.c:2240) */
+    uint16_t nterm;      /* = lref */
+    uint16_t start[2];   /* cblk->data_start[1 .. nterm] (really nterm entries) */
+} J2kPart1Trailer;
+#define J2K_P1_TRAILER_OFF(len)      ((((size_t)(len)) + 2 + 3) & ~(size_t)3)
+#define J2K_P1_REGION(len, nterm)    ((J2K_P1_TRAILER_OFF(len) + 4 + 2 * (size_t)(nterm) + J2K_BLOCK_PAD + 15) & ~(size_t)15)
 
 /* One tile-component = one coefficient plane + its DWT geometry */
 typedef struct J2kTileComp {
@@ -90,6 +108,7 @@ typedef struct J2kPlan {
      * Computed while the block bytes are hot in cache, so that the device layer never has to touch the
      * byte pool again (jpeg2000htdec.c:1252-1273 for the Scup rules) */
     uint32_t max_pcup, max_scup, max_qw, max_bm_words;
+    int32_t  have_part1;         /* some blocks are Part-1 (MQ) coded: J2K_BLK_PART1 */
     uint32_t palette[256];
 } J2kPlan;
 

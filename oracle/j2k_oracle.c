@@ -618,6 +618,11 @@ done:
     return ret;
 }
 
+/* Part-1 (MQ) block decoder: j2k_oracle_mq.c */
+int orc_mq_decode_block(uint8_t *data, int length, int npasses, int nonzerobits, int width, int height,
+                        int M_b, int roi_shift, int style, int bandpos, int nterm, const uint16_t *data_start,
+                        int32_t *out, int out_stride);
+
 /* ================================================================== dequantisation
  * jpeg2000dec.c:2098-2181: src = sign-magnitude block, dst = window of the plane */
 ORC_EXPORT void orc_dequant_float(const int32_t *src, int sstride, float *dst, int dstride,
@@ -926,11 +931,20 @@ ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size
         int transform = b->flags & 3;
         if (!b->npasses)
             continue;                               /* not coded: plane stays zero (av_calloc) */
-        memcpy(scratch, pl->bytes + b->data_off, (size_t)b->lcup + b->lref + 8);
-        ret = orc_ht_decode_block(scratch, b->lcup, b->lref, b->npasses, b->zbp, b->w, b->h, b->M_b,
-                                  b->roi_shift, b->flags & J2K_CBLK_VSC, t1, b->w);
+        if (b->flags & J2K_BLK_PART1) {
+            const J2kPart1Trailer *tr = (const J2kPart1Trailer *)(pl->bytes + b->data_off + J2K_P1_TRAILER_OFF(b->lcup));
+            memcpy(scratch, pl->bytes + b->data_off, (size_t)b->lcup + 8);
+            /* data_start[0] is never read (jpeg2000dec.c:2044-2053 uses [term_cnt + 1] only) */
+            ret = orc_mq_decode_block(scratch, b->lcup, b->npasses, b->zbp, b->w, b->h, b->M_b, b->roi_shift,
+                                      tr->style, tr->bandpos, tr->nterm, tr->start - 1, t1, b->w);
+        } else {
+            memcpy(scratch, pl->bytes + b->data_off, (size_t)b->lcup + b->lref + 8);
+            ret = orc_ht_decode_block(scratch, b->lcup, b->lref, b->npasses, b->zbp, b->w, b->h, b->M_b,
+                                      b->roi_shift, b->flags & J2K_CBLK_VSC, t1, b->w);
+        }
         if (ret < 0)
-            f->n_block_errors++;                    /* block left zero, frame continues (jpeg2000dec.c:2275-2278) */
+            f->n_block_errors++;                    /* HT: block left zero; Part-1: the passes decoded so far stay
+                                                     * (jpeg2000dec.c:2275-2278); the frame continues either way */
         if (ret == 0)
             continue;
         if (transform == J2K_DWT97)

@@ -440,6 +440,302 @@ static int ht_refine_encode(const uint32_t *full, const uint8_t *sgn, int w, int
     return ret;
 }
 
+/* ------------------------------------------------------------------ Part-1 (EBCOT / MQ) block encoder
+ * T.800 Annex C (MQ coder, software conventions) and Annex D (coding passes), written from the
+ * standard: per-sample state arrays and neighbour counts, not the decoder's flag words.
+ * Mode switches honoured: BYPASS 0x01, RESET 0x02, TERMALL 0x04, VSC 0x08, SEGSYM 0x20.
+ * Every terminated MQ segment uses the full FLUSH of C.2.9 (always decodable; a trailing 0xFF is
+ * dropped); raw segments are padded with 1 bits, which is what a decoder reads past the end. */
+typedef struct MqRowE { uint16_t qe; uint8_t nmps, nlps, sw; } MqRowE;
+static const MqRowE MQE[47] = {
+    { 0x5601,  1,  1, 1 }, { 0x3401,  2,  6, 0 }, { 0x1801,  3,  9, 0 }, { 0x0AC1,  4, 12, 0 }, { 0x0521,  5, 29, 0 },
+    { 0x0221, 38, 33, 0 }, { 0x5601,  7,  6, 1 }, { 0x5401,  8, 14, 0 }, { 0x4801,  9, 14, 0 }, { 0x3801, 10, 14, 0 },
+    { 0x3001, 11, 17, 0 }, { 0x2401, 12, 18, 0 }, { 0x1C01, 13, 20, 0 }, { 0x1601, 29, 21, 0 }, { 0x5601, 15, 14, 1 },
+    { 0x5401, 16, 14, 0 }, { 0x5101, 17, 15, 0 }, { 0x4801, 18, 16, 0 }, { 0x3801, 19, 17, 0 }, { 0x3401, 20, 18, 0 },
+    { 0x3001, 21, 19, 0 }, { 0x2801, 22, 19, 0 }, { 0x2401, 23, 20, 0 }, { 0x2201, 24, 21, 0 }, { 0x1C01, 25, 22, 0 },
+    { 0x1801, 26, 23, 0 }, { 0x1601, 27, 24, 0 }, { 0x1401, 28, 25, 0 }, { 0x1201, 29, 26, 0 }, { 0x1101, 30, 27, 0 },
+    { 0x0AC1, 31, 28, 0 }, { 0x09C1, 32, 29, 0 }, { 0x08A1, 33, 30, 0 }, { 0x0521, 34, 31, 0 }, { 0x0441, 35, 32, 0 },
+    { 0x02A1, 36, 33, 0 }, { 0x0221, 37, 34, 0 }, { 0x0141, 38, 35, 0 }, { 0x0111, 39, 36, 0 }, { 0x0085, 40, 37, 0 },
+    { 0x0049, 41, 38, 0 }, { 0x0025, 42, 39, 0 }, { 0x0015, 43, 40, 0 }, { 0x0009, 44, 41, 0 }, { 0x0005, 45, 42, 0 },
+    { 0x0001, 45, 43, 0 }, { 0x5601, 46, 46, 0 },
+};
+#define P1_UNI 17
+#define P1_RL  18
+
+typedef struct MqE {
+    uint32_t A, C;
+    int CT;
+    uint8_t *buf;            /* buf[0] is the dummy byte in front of the codeword */
+    size_t bp, cap;
+    uint8_t I[19], MPS[19];
+    /* raw (bypass) writer state */
+    uint32_t rtmp; int rbits, rmax;
+    int raw;
+} MqE;
+
+static void mqe_contexts(MqE *m)
+{
+    memset(m->I, 0, sizeof(m->I)); memset(m->MPS, 0, sizeof(m->MPS));
+    m->I[P1_UNI] = 46; m->I[P1_RL] = 3; m->I[0] = 4;
+}
+static void mqe_room(MqE *m)
+{
+    if (m->bp + 8 > m->cap) { m->cap = m->cap ? 2 * m->cap : 8192; m->buf = (uint8_t *)realloc(m->buf, m->cap); }
+}
+static void mqe_start(MqE *m, int raw)       /* INITENC; the byte in front of a fresh segment is a dummy 0 */
+{
+    mqe_room(m);
+    m->bp = 0; m->buf[0] = 0;
+    m->A = 0x8000; m->C = 0; m->CT = 12;
+    m->raw = raw; m->rtmp = 0; m->rbits = 0; m->rmax = 8;
+}
+static void mqe_byteout(MqE *m)
+{
+    mqe_room(m);
+    if (m->buf[m->bp] == 0xFF) {
+        m->buf[++m->bp] = (uint8_t)(m->C >> 20); m->C &= 0xFFFFF; m->CT = 7;
+    } else if (!(m->C & 0x8000000)) {
+        m->buf[++m->bp] = (uint8_t)(m->C >> 19); m->C &= 0x7FFFF; m->CT = 8;
+    } else {
+        m->buf[m->bp]++;
+        if (m->buf[m->bp] == 0xFF) {
+            m->C &= 0x7FFFFFF;
+            m->buf[++m->bp] = (uint8_t)(m->C >> 20); m->C &= 0xFFFFF; m->CT = 7;
+        } else {
+            m->buf[++m->bp] = (uint8_t)(m->C >> 19); m->C &= 0x7FFFF; m->CT = 8;
+        }
+    }
+}
+static void mqe_renorm(MqE *m)
+{
+    do {
+        m->A <<= 1; m->C <<= 1;
+        if (--m->CT == 0) mqe_byteout(m);
+    } while (!(m->A & 0x8000));
+}
+static void mqe_put(MqE *m, int cx, int d)
+{
+    if (m->raw) {                               /* bypass: MSB first, 7 bits in the byte after an 0xFF */
+        m->rtmp = (m->rtmp << 1) | (uint32_t)(d & 1);
+        if (++m->rbits == m->rmax) {
+            mqe_room(m);
+            m->buf[++m->bp] = (uint8_t)m->rtmp;
+            m->rmax = m->rtmp == 0xFF ? 7 : 8;
+            m->rtmp = 0; m->rbits = 0;
+        }
+        return;
+    }
+    {
+        const MqRowE *r = &MQE[m->I[cx]];
+        m->A -= r->qe;
+        if (d == m->MPS[cx]) {
+            if (!(m->A & 0x8000)) {
+                if (m->A < r->qe) m->A = r->qe; else m->C += r->qe;
+                m->I[cx] = r->nmps;
+                mqe_renorm(m);
+            } else {
+                m->C += r->qe;
+            }
+        } else {
+            if (m->A < r->qe) m->C += r->qe; else m->A = r->qe;
+            if (r->sw) m->MPS[cx] ^= 1;
+            m->I[cx] = r->nlps;
+            mqe_renorm(m);
+        }
+    }
+}
+/* terminate the running segment and append it to `out`; returns its length */
+static int mqe_finish(MqE *m, Buf *out)
+{
+    size_t n;
+    if (m->raw) {
+        if (m->rbits) {
+            mqe_room(m);
+            m->buf[++m->bp] = (uint8_t)((m->rtmp << (m->rmax - m->rbits)) | ((1u << (m->rmax - m->rbits)) - 1));
+        }
+    } else {
+        uint32_t t = m->C + m->A;
+        m->C |= 0xFFFF;
+        if (m->C >= t) m->C -= 0x8000;
+        m->C <<= m->CT; mqe_byteout(m);
+        m->C <<= m->CT; mqe_byteout(m);
+    }
+    n = m->bp;
+    while (n > 0 && m->buf[n] == 0xFF) n--;     /* a segment never ends in 0xFF: the decoder supplies it */
+    buf_put(out, m->buf + 1, n);
+    return (int)n;
+}
+
+typedef struct P1 {
+    int w, h, style, band;                      /* band: 0 LL, 1 HL, 2 LH, 3 HH */
+    const uint32_t *mag; const uint8_t *sgn;
+    uint8_t *sig, *vis, *ref;                   /* (w + 2) x (h + 2) with a zero border */
+    MqE mq;
+} P1;
+#define P1AT(a, x, y) ((a)[((y) + 1) * (p->w + 2) + (x) + 1])
+
+/* significance of the 8 neighbours; under VSC the row below the last row of a stripe does not exist */
+static void p1_nbr(const P1 *p, int x, int y, int *hh, int *vv, int *dd, int *hc, int *vc)
+{
+    const int south = !((p->style & 0x08) && (y & 3) == 3);
+    int n = P1AT(p->sig, x, y - 1), s = south ? P1AT(p->sig, x, y + 1) : 0;
+    int w_ = P1AT(p->sig, x - 1, y), e = P1AT(p->sig, x + 1, y);
+    int sgn_at[4];
+    *hh = w_ + e; *vv = n + s;
+    *dd = P1AT(p->sig, x - 1, y - 1) + P1AT(p->sig, x + 1, y - 1) +
+          (south ? P1AT(p->sig, x - 1, y + 1) + P1AT(p->sig, x + 1, y + 1) : 0);
+    sgn_at[0] = (x > 0 && w_) ? (p->sgn[y * p->w + x - 1] ? -1 : 1) : 0;
+    sgn_at[1] = (x + 1 < p->w && e) ? (p->sgn[y * p->w + x + 1] ? -1 : 1) : 0;
+    sgn_at[2] = (y > 0 && n) ? (p->sgn[(y - 1) * p->w + x] ? -1 : 1) : 0;
+    sgn_at[3] = (y + 1 < p->h && s) ? (p->sgn[(y + 1) * p->w + x] ? -1 : 1) : 0;
+    *hc = imax(-1, imin(1, sgn_at[0] + sgn_at[1]));
+    *vc = imax(-1, imin(1, sgn_at[2] + sgn_at[3]));
+}
+static int p1_zc(const P1 *p, int x, int y)     /* T.800 Table D.1 */
+{
+    int h, v, d, hc, vc;
+    p1_nbr(p, x, y, &h, &v, &d, &hc, &vc);
+    if (p->band == 1) { int t = h; h = v; v = t; }
+    if (p->band < 3) {
+        if (h == 2) return 8;
+        if (h == 1) return v >= 1 ? 7 : d >= 1 ? 6 : 5;
+        if (v == 2) return 4;
+        if (v == 1) return 3;
+        return d >= 2 ? 2 : d;
+    }
+    if (d >= 3) return 8;
+    if (d == 2) return h + v >= 1 ? 7 : 6;
+    if (d == 1) return h + v >= 2 ? 5 : h + v == 1 ? 4 : 3;
+    return h + v >= 2 ? 2 : h + v;
+}
+static void p1_sign(P1 *p, int x, int y)        /* T.800 Tables D.2 / D.3 */
+{
+    static const uint8_t lab[3][3] = { { 13, 12, 11 }, { 10, 9, 10 }, { 11, 12, 13 } };
+    int h, v, d, hc, vc, x_or, bit = p->sgn[y * p->w + x];
+    p1_nbr(p, x, y, &h, &v, &d, &hc, &vc);
+    x_or = hc < 0 || (hc == 0 && vc < 0);
+    mqe_put(&p->mq, lab[hc + 1][vc + 1], p->mq.raw ? bit : bit ^ x_or);
+}
+static void p1_sigpass(P1 *p, int bp)
+{
+    int y0, x, y;
+    for (y0 = 0; y0 < p->h; y0 += 4)
+        for (x = 0; x < p->w; x++)
+            for (y = y0; y < imin(y0 + 4, p->h); y++) {
+                int h, v, d, hc, vc;
+                if (P1AT(p->sig, x, y)) continue;
+                p1_nbr(p, x, y, &h, &v, &d, &hc, &vc);
+                if (h + v + d == 0) continue;
+                {
+                    int bit = (p->mag[y * p->w + x] >> bp) & 1;
+                    mqe_put(&p->mq, p1_zc(p, x, y), bit);
+                    if (bit) { p1_sign(p, x, y); P1AT(p->sig, x, y) = 1; }
+                    P1AT(p->vis, x, y) = 1;
+                }
+            }
+}
+static void p1_refpass(P1 *p, int bp)
+{
+    int y0, x, y;
+    for (y0 = 0; y0 < p->h; y0 += 4)
+        for (x = 0; x < p->w; x++)
+            for (y = y0; y < imin(y0 + 4, p->h); y++) {
+                int h, v, d, hc, vc;
+                if (!P1AT(p->sig, x, y) || P1AT(p->vis, x, y)) continue;
+                p1_nbr(p, x, y, &h, &v, &d, &hc, &vc);
+                mqe_put(&p->mq, P1AT(p->ref, x, y) ? 16 : (h + v + d) ? 15 : 14, (p->mag[y * p->w + x] >> bp) & 1);
+                P1AT(p->ref, x, y) = 1;
+            }
+}
+static void p1_clnpass(P1 *p, int bp)
+{
+    int y0, x, y;
+    for (y0 = 0; y0 < p->h; y0 += 4)
+        for (x = 0; x < p->w; x++) {
+            int first = y0;
+            if (y0 + 3 < p->h) {
+                int quiet = 1;
+                for (y = y0; y < y0 + 4; y++) {
+                    int h, v, d, hc, vc;
+                    p1_nbr(p, x, y, &h, &v, &d, &hc, &vc);
+                    if (P1AT(p->sig, x, y) || P1AT(p->vis, x, y) || h + v + d) quiet = 0;
+                }
+                if (quiet) {
+                    int r = 4;
+                    for (y = y0; y < y0 + 4; y++)
+                        if ((p->mag[y * p->w + x] >> bp) & 1) { r = y - y0; break; }
+                    mqe_put(&p->mq, P1_RL, r < 4);
+                    if (r == 4) continue;
+                    mqe_put(&p->mq, P1_UNI, r >> 1);
+                    mqe_put(&p->mq, P1_UNI, r & 1);
+                    p1_sign(p, x, y0 + r);
+                    P1AT(p->sig, x, y0 + r) = 1;
+                    first = y0 + r + 1;
+                }
+            }
+            for (y = first; y < imin(y0 + 4, p->h); y++) {
+                if (!P1AT(p->sig, x, y) && !P1AT(p->vis, x, y)) {
+                    int bit = (p->mag[y * p->w + x] >> bp) & 1;
+                    mqe_put(&p->mq, p1_zc(p, x, y), bit);
+                    if (bit) { p1_sign(p, x, y); P1AT(p->sig, x, y) = 1; }
+                }
+            }
+        }
+    memset(p->vis, 0, (size_t)(p->w + 2) * (p->h + 2));
+    if (p->style & 0x20) {
+        mqe_put(&p->mq, P1_UNI, 1); mqe_put(&p->mq, P1_UNI, 0); mqe_put(&p->mq, P1_UNI, 1); mqe_put(&p->mq, P1_UNI, 0);
+    }
+}
+
+#define P1_MAX_SEGS 100
+/* mag/sgn: w x h.  Codes the passes of bit-planes K-1 .. 0 (all but the last `drop` passes) into `out`;
+ * fills seglen[] / segpasses[] with the codeword segments in the order a packet header signals them. */
+static int p1_encode_block(const uint32_t *mag, const uint8_t *sgn, int w, int h, int band, int style, int drop,
+                           Buf *out, int *kbits, int *npasses, int *nseg, int *seglen, int *segpasses)
+{
+    P1 P, *p = &P;
+    uint32_t mx = 0;
+    int i, K, total, pass, in_seg = 0;
+    size_t cells = (size_t)(w + 2) * (h + 2);
+    for (i = 0; i < w * h; i++) if (mag[i] > mx) mx = mag[i];
+    K = bitlen32(mx);
+    *kbits = K; *npasses = 0; *nseg = 0;
+    if (!K) return 0;
+    total = 3 * K - 2 - drop;
+    if (total < 1) total = 1;
+    if (total > P1_MAX_SEGS - 1) return -6;
+    memset(p, 0, sizeof(*p));
+    p->w = w; p->h = h; p->style = style; p->band = band; p->mag = mag; p->sgn = sgn;
+    p->sig = (uint8_t *)calloc(cells, 1); p->vis = (uint8_t *)calloc(cells, 1); p->ref = (uint8_t *)calloc(cells, 1);
+    if (!p->sig || !p->vis || !p->ref) { free(p->sig); free(p->vis); free(p->ref); return -1; }
+    mqe_contexts(&p->mq);
+    mqe_start(&p->mq, 0);
+    for (pass = 0; pass < total; pass++) {
+        const int type = pass % 3;                 /* 0 cleanup, 1 significance propagation, 2 magnitude refinement */
+        const int bp = K - 1 - (pass + 2) / 3;
+        int term;
+        if (type == 0) p1_clnpass(p, bp); else if (type == 1) p1_sigpass(p, bp); else p1_refpass(p, bp);
+        in_seg++;
+        if (style & 0x02) mqe_contexts(&p->mq);
+        /* where a codeword segment ends (T.800 Table D.8 / D.9) */
+        term = pass == total - 1 || (style & 0x04) != 0;
+        if ((style & 0x01) && pass >= 9 && type != 1) term = 1;    /* in front of and behind each raw SP + MR pair */
+        if (term) {
+            seglen[*nseg] = mqe_finish(&p->mq, out);
+            segpasses[*nseg] = in_seg;
+            (*nseg)++;
+            in_seg = 0;
+            if (pass + 1 < total) {
+                const int ntype = (pass + 1) % 3;
+                mqe_start(&p->mq, (style & 0x01) && pass + 1 >= 10 && ntype != 0);
+            }
+        }
+    }
+    *npasses = total;
+    free(p->sig); free(p->vis); free(p->ref); free(p->mq.buf);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ transforms (forward) */
 /* Lifting on a symmetric extension: positions [lo,hi] hold valid data; every step
  * updates one parity on [lo+1,hi-1] and shrinks the valid range by one on both sides. */
@@ -623,6 +919,8 @@ typedef struct ECblk {
     int lcup, lref, npasses;   /* npasses includes placeholder passes */
     int zbp;
     int included;
+    /* Part-1 blocks: magnitude bit-planes coded and the codeword segments in signalling order */
+    int kbits, nseg, seglen[P1_MAX_SEGS], segpasses[P1_MAX_SEGS];
 } ECblk;
 typedef struct EPrec { int ncw, nch; ECblk *cb; TagTree incl, zbp; } EPrec;
 typedef struct EBand { int x0, x1, y0, y1; int xob, yob; int cbw, cbh; float fstep; int expn, mant, M_b; EPrec *prec; int offx, offy; } EBand;
@@ -675,6 +973,14 @@ static int encode_block(const htj2k_enc_params *P, const EBand *bd, ECblk *cb,
             any_full |= m != 0;
         }
     cb->included = 0; cb->npasses = 0; cb->lcup = cb->lref = 0;
+    if (P->part1) {
+        ret = p1_encode_block(full, sgn, w, h, bd->xob + 2 * bd->yob, P->cblk_style & 0x3F, P->p1_drop_passes,
+                              &cb->data, &cb->kbits, &cb->npasses, &cb->nseg, cb->seglen, cb->segpasses);
+        cb->included = !ret && any_full;
+        if (cb->kbits > *need_Mb) *need_Mb = cb->kbits;
+        free(full); free(mag); free(sgn);
+        return ret;
+    }
     (void)any_full;
     if (!any && !P->force_include) { free(full); free(mag); free(sgn); return 0; }
     /* (an all-zero cleanup pass is legal: MEL codes every quad as empty) */
@@ -741,6 +1047,18 @@ static void write_packet(const htj2k_enc_params *P, ERes *rs, int precno, Buf *o
             else if (np <= 5) { bw_bits(&bw, 3, 2); bw_bits(&bw, (uint32_t)(np - 3), 2); }
             else if (np <= 36) { bw_bits(&bw, 0xF, 4); bw_bits(&bw, (uint32_t)(np - 6), 5); }
             else { bw_bits(&bw, 0x1FF, 9); bw_bits(&bw, (uint32_t)(np - 37), 7); }
+            if (P->part1) {
+                /* T.800 B.10.7: one length per codeword segment, lblock + floor(log2(passes in it)) bits */
+                int sg;
+                need = 0;
+                for (sg = 0; sg < cb->nseg; sg++)
+                    need = imax(need, bitlen32((uint32_t)cb->seglen[sg]) - (bitlen32((uint32_t)cb->segpasses[sg]) - 1));
+                for (extra = imax(0, need - lblock); extra > 0; extra--) { bw_bit(&bw, 1); lblock++; }
+                bw_bit(&bw, 0);
+                for (sg = 0; sg < cb->nseg; sg++)
+                    bw_bits(&bw, (uint32_t)cb->seglen[sg], lblock + bitlen32((uint32_t)cb->segpasses[sg]) - 1);
+                continue;
+            }
             /* HT segment lengths: the first field has lblock + floor(log2(passes in the
              * first segment incl. placeholders)) bits, refinement has lblock (+1 for 2 passes) */
             {
@@ -992,7 +1310,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
                         for (k = 0; k < pr->ncw * pr->nch; k++) {
                             ECblk *cb = &pr->cb[k];
                             int pp = P->passes > 1 ? 1 : 0;
-                            cb->zbp = bd->M_b - 1 - pp - P->placeholder_sets;
+                            cb->zbp = P->part1 ? bd->M_b - cb->kbits : bd->M_b - 1 - pp - P->placeholder_sets;
                             tt_set(&pr->incl, k, cb->included ? 0 : 1);
                             if (cb->included) tt_set(&pr->zbp, k, imax(cb->zbp, 0));
                             if (cb->included && cb->zbp < 0) ret = -5;
@@ -1094,7 +1412,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
         buf_u8(&out, P->dy[c] ? P->dy[c] : 1);
     }
     /* CAP: Part 15; Ccap15 bit 5 = HTIRV when 9/7 is used; MAGB field from the largest M_b */
-    {
+    if (!P->part1) {
         int maxMb = 1, Pm;
         for (c = 0; c < P->ncomp; c++)
             for (r = 0; r < 3 * NL + 1; r++)
@@ -1111,7 +1429,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
     buf_u8(&out, P->mct ? 1 : 0);
     buf_u8(&out, NL);
     buf_u8(&out, P->cb_w_log2 - 2); buf_u8(&out, P->cb_h_log2 - 2);
-    buf_u8(&out, 0x40 | (P->cblk_style & 0x08));
+    buf_u8(&out, P->part1 ? (P->cblk_style & 0x3F) : (0x40 | (P->cblk_style & 0x08)));
     buf_u8(&out, P->transform);
     if (P->nprec)
         for (r = 0; r < nres; r++)

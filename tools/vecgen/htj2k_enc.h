@@ -34,6 +34,9 @@ typedef struct htj2k_enc_params {
     int rsiz;
     int cap_extra_bits;         /* OR'ed into Ccap15 bits 11..15 (test error paths) */
     const char *comment;
+    int part1;                  /* 1: Part-1 (MQ-coded) blocks, no CAP marker; cblk_style then honours BYPASS 0x01,
+                                 * RESET 0x02, TERMALL 0x04, VSC 0x08, SEGSYM 0x20 */
+    int p1_drop_passes;         /* Part-1: leave out the last N coding passes of every block (lossy truncation) */
 } htj2k_enc_params;
 
 /* comps[c]: int32 samples of component c, row-major, ceil(X1/dx)-ceil(X0/dx) wide.
