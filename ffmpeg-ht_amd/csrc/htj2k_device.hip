@@ -26,6 +26,7 @@
 #include "dwt_kernels.hpp"
 #include "pack_kernels.hpp"
 #include "dwt_stream.hpp"
+#include "mq_kernels.hpp"
 
 using namespace htj2k;
 
@@ -124,6 +125,11 @@ struct htj2k_job {
     int lev_ev_used = 0;
     std::vector<double> lev_bytes, lev_hbm;   /* algorithmic / least-HBM bytes of each recorded launch */
     DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_vlcu, d_melu, d_reflist, d_roff, d_refbits;
+    /* Part-1 (MQ-coded) blocks sit behind the HT blocks in `blocks`: [nht, blocks.size()) */
+    int nht = 0;
+    std::vector<MqWave> mqwaves;       /* one per 64 Part-1 blocks */
+    size_t mq_scratch_units = 0;       /* 512-byte row slots of k_mq_decode's scratch */
+    DevBuf d_mqwaves, d_mqscratch;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
     size_t nrefmasks = 0;
@@ -282,6 +288,7 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     j->d_bytes.release(); j->d_blocks.release(); j->d_status.release(); j->d_coef.release();
     j->d_t0.release(); j->d_t1.release(); j->d_desc.release(); j->d_qsym.release(); j->d_qoff.release();
     j->d_vlcu.release(); j->d_melu.release(); j->d_reflist.release(); j->d_roff.release(); j->d_refbits.release();
+    j->d_mqwaves.release(); j->d_mqscratch.release();
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
@@ -384,11 +391,6 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
         }
         for (int f = 0; f < n; f++)
             if (rc[f] < 0) return rc[f];                   /* the first failing frame in submission order */
-        for (int f = 0; f < n; f++)
-            if (j->frames[f].plan->have_part1) {
-                clog(c, 16, "Part-1 (MQ-coded) codeblocks present: not handled by the HIP path yet\n");
-                return HTJ2K_ERR_PATCHWELCOME;
-            }
     }
     for (int f = 0; f < n; f++) {
         FrameSlot &F = j->frames[f];
@@ -793,12 +795,45 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
             for (const J2kBlock &b : tmp) j->blocks[cnt[maxq - quads(b)]++] = b;
         }
+        /* Part-1 blocks behind the HT blocks, ordered so that the 64 lanes of a k_mq_decode wave walk blocks of
+         * one size with similar pass counts (the sort above already grouped sizes) */
+        {
+            auto part1 = [](const J2kBlock &b) { return (b.flags & J2K_BLK_PART1) != 0; };
+            auto mid = std::stable_partition(j->blocks.begin(), j->blocks.end(), [&](const J2kBlock &b) { return !part1(b); });
+            j->nht = (int)(mid - j->blocks.begin());
+            std::stable_sort(mid, j->blocks.end(), [&](const J2kBlock &a, const J2kBlock &b) {
+                if (a.h != b.h) return a.h > b.h;
+                if (a.w != b.w) return a.w > b.w;
+                return a.npasses > b.npasses;
+            });
+            j->mqwaves.clear();
+            size_t units = 0;
+            for (size_t i = (size_t)j->nht; i < j->blocks.size(); i += 64) {
+                MqWave W;
+                int hmax = 0, wmax = 0, pmax = 0;
+                for (size_t k = i; k < std::min(i + 64, j->blocks.size()); k++) {
+                    const J2kBlock &b = j->blocks[k];
+                    if (b.w > 64) {
+                        clog(c, 16, "Part-1 codeblock wider than 64 columns (%d x %d): not handled by the HIP path\n", b.w, b.h);
+                        return HTJ2K_ERR_PATCHWELCOME;
+                    }
+                    hmax = std::max<int>(hmax, b.h); wmax = std::max<int>(wmax, b.w); pmax = std::max<int>(pmax, b.npasses);
+                }
+                W.hmax = (uint16_t)hmax; W.wmax = (uint16_t)wmax; W.pmax = (uint16_t)pmax;
+                W.rows = (uint16_t)(((hmax + 3) & ~3) + 2);
+                if (units > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
+                W.soff = (uint32_t)units;
+                units += (size_t)(4 + std::min((pmax + 1) / 3 + 1, 32)) * W.rows;
+                j->mqwaves.push_back(W);
+            }
+            j->mq_scratch_units = units;
+        }
         j->qoff.resize(j->blocks.size() + 1);
         size_t q = 0;
         for (size_t i = 0; i < j->blocks.size(); i++) {
             j->qoff[i] = (uint32_t)q;
             const J2kBlock &b = j->blocks[i];
-            if (b.npasses) q += ht_qsym_words(b.w, b.h);
+            if (b.npasses && !(b.flags & J2K_BLK_PART1)) q += ht_qsym_words(b.w, b.h);
         }
         if (q > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
         j->nquads = q;
@@ -811,7 +846,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             const J2kBlock &b = j->blocks[i];
             const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
             j->roff[i] = (uint32_t)nm;
-            if (b.npasses && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
+            if (b.npasses && !(b.flags & J2K_BLK_PART1) && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
                 j->reflist.push_back((uint32_t)i);
                 nm += (size_t)3 * b.h;
             }
@@ -821,7 +856,10 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     }
     const size_t coef_bytes = (j->nsamples + 64) * sizeof(uint32_t);
     const int nblocks = (int)j->blocks.size();
-    if ((r = j->d_bytes.ensure(j->nbytes + 64)) < 0) return r;
+    if ((r = j->d_bytes.ensure(j->nbytes + 256)) < 0) return r;        /* k_mq_decode's 128-byte windows start inside a block */
+    if (!j->mqwaves.empty() &&
+        ((r = j->d_mqwaves.ensure(j->mqwaves.size() * sizeof(MqWave))) < 0 ||
+         (r = j->d_mqscratch.ensure(j->mq_scratch_units * 512 + 512)) < 0)) return r;
     if ((r = j->d_blocks.ensure((size_t)(nblocks + 1) * sizeof(J2kBlock))) < 0) return r;
     if ((r = j->d_status.ensure((size_t)(nblocks + 1) * sizeof(int))) < 0) return r;
     if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
@@ -863,6 +901,8 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         HIP_TRY(c, hipMemcpyAsync(j->d_roff.p, j->roff.data(), j->roff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
         if (!j->reflist.empty())
             HIP_TRY(c, hipMemcpyAsync(j->d_reflist.p, j->reflist.data(), j->reflist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+        if (!j->mqwaves.empty())
+            HIP_TRY(c, hipMemcpyAsync(j->d_mqwaves.p, j->mqwaves.data(), j->mqwaves.size() * sizeof(MqWave), hipMemcpyHostToDevice, j->stream));
     }
     HIP_TRY(c, hipEventRecord(j->ev[1], j->stream));
     j->uploaded = 1;
@@ -997,12 +1037,20 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
 extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
 {
     if (!c || !j || j->nframes <= 0 || !j->uploaded) return HTJ2K_ERR_EINVAL;
-    const int nblocks = (int)j->blocks.size(), ntc = (int)j->tilecomps.size();
+    const int nall = (int)j->blocks.size(), ntc = (int)j->tilecomps.size();
+    const int nblocks = j->nht;                        /* HT blocks; the Part-1 blocks follow */
     HIP_TRY(c, hipSetDevice(c->device));
     if (mask & 1) {
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
+        if (nall) HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nall * sizeof(int), j->stream));
+        if (nall > nblocks) {
+            hipLaunchKernelGGL(k_mq_decode, dim3((unsigned)j->mqwaves.size()), dim3(64), MQ_LDS_BYTES, j->stream,
+                               (const J2kBlock *)j->d_blocks.p + nblocks, nall - nblocks, (const uint8_t *)j->d_bytes.p,
+                               (uint32_t *)j->d_coef.p, (int *)j->d_status.p + nblocks, (const MqWave *)j->d_mqwaves.p,
+                               (uint64_t *)j->d_mqscratch.p);
+            HIP_TRY(c, hipGetLastError());
+        }
         if (nblocks) {
-            HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nblocks * sizeof(int), j->stream));
             const size_t vlc_lds = ht_vlc_lds_bytes(j->max_qw);
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)

@@ -68,6 +68,32 @@ CASES = {
     "gray_97_offset":    (lambda: _enc((201, 149, 1, 8, 4), nlevels=3, offset=(3, 5), transform=0, qstep=1), {}),
     "gray_97_bitexact":  (lambda: _enc((200, 150, 1, 8, 3), transform=0, qstep=2), {"bitexact": 1}),
     "rgb_97_bitexact":   (lambda: _enc((190, 131, 3, 8, 5), transform=0, mct=1, qstep=1), {"bitexact": 1}),
+    # --- Part-1 (MQ-coded) blocks: decode_cblk() instead of the HT decoder; style bits BYPASS 1, RESET 2,
+    #     TERMALL 4, VSC 8, SEGSYM 0x20 ---
+    "p1_gray":            (lambda: _enc((200, 150, 1, 8, 3), part1=True), {}),
+    "p1_gray_cb32":       (lambda: _enc((200, 150, 1, 8, 3), part1=True, cb=(5, 5)), {}),
+    "p1_gray_cb16x64":    (lambda: _enc((200, 150, 1, 8, 3), part1=True, cb=(4, 6), nlevels=3), {}),
+    "p1_gray_cb64x4":     (lambda: _enc((200, 150, 1, 8, 3), part1=True, cb=(6, 2), nlevels=2), {}),
+    "p1_gray_cb4x1024":   (lambda: _enc((40, 1100, 1, 8, 14), part1=True, cb=(2, 10), nlevels=2), {}),
+    "p1_bypass":          (lambda: _enc((200, 150, 1, 12, 3, 60), depth=12, part1=True, cblk_style=0x01), {}),
+    "p1_reset":           (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x02), {}),
+    "p1_termall":         (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x04), {}),
+    "p1_vsc":             (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x08), {}),
+    "p1_segsym":          (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x20), {}),
+    "p1_bypass_termall":  (lambda: _enc((200, 150, 1, 12, 3, 60), depth=12, part1=True, cblk_style=0x05), {}),
+    "p1_all_switches":    (lambda: _enc((160, 120, 1, 16, 8, 400), depth=16, nlevels=4, part1=True, cblk_style=0x2F), {}),
+    "p1_rgb_mct":         (lambda: _enc((190, 131, 3, 8, 5), mct=1, part1=True), {}),
+    "p1_rgb_tiles":       (lambda: _enc((190, 131, 3, 8, 6), mct=1, tile=(100, 70), nlevels=3, offset=(7, 9), tile_offset=(2, 3), part1=True), {}),
+    "p1_yuv420":          (lambda: _enc((190, 130, 3, 8, 12, 8, (1, 2, 2), (1, 2, 2)), dx=[1, 2, 2], dy=[1, 2, 2], width=190, height=130, part1=True), {}),
+    "p1_truncated_1":     (lambda: _enc((200, 150, 1, 8, 3), part1=True, drop_passes=1), {}),
+    "p1_truncated_2":     (lambda: _enc((200, 150, 1, 8, 3), part1=True, drop_passes=2, cblk_style=0x04), {}),
+    "p1_truncated_5":     (lambda: _enc((200, 150, 1, 8, 3), part1=True, drop_passes=5), {}),
+    "p1_97":              (lambda: _enc((200, 150, 1, 8, 3), part1=True, transform=0, qstep=1), {}),
+    "p1_97_rgb_bitexact": (lambda: _enc((190, 131, 3, 8, 5), part1=True, transform=0, mct=1, qstep=1), {"bitexact": 1}),
+    "p1_lowres_2":        (lambda: _enc((190, 131, 3, 8, 5), mct=1, part1=True), {"reduction_factor": 2}),
+    "p1_noise_max":       (lambda: vecgen.encode([np.random.default_rng(2).integers(0, 256, (130, 130))], nlevels=3, part1=True), {}),
+    "p1_all_zero":        (lambda: vecgen.encode([np.full((100, 100), 128)], nlevels=3, part1=True), {}),
+    "p1_tiny_3x1":        (lambda: vecgen.encode([np.array([[77, 3, 250]])], nlevels=2, part1=True), {}),
 }
 
 

@@ -354,6 +354,78 @@ def test_truncated_and_garbage_streams_do_not_fault(dec, orc):
         assert planes[0].shape == planes_o[0].shape
 
 
+# ---------------------------------------------------------------- Part-1 (MQ-coded) blocks: k_mq_decode
+OPJ = np.load(os.path.join(HERE, "golden", "opj_part1.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(k[:-4] for k in OPJ.files if k.endswith(".j2k")))
+def test_openjpeg_encoded_part1_streams(dec, orc, name):
+    """streams written by a third-party encoder (OpenJPEG, tests/golden/make_openjpeg_part1.py): the device path
+    equals the oracle bit for bit (9/7 included) and both equal the pixels stored with the stream"""
+    data = OPJ[name + ".j2k"].tobytes()
+    pix = OPJ[name + ".pix"]
+    info_o, planes_o, _ = orc.decode(data)
+    info, planes, _, st = dec.decode(data)
+    assert st.n_block_errors == 0
+    for a, b in zip(planes, planes_o):
+        assert np.array_equal(a, b)
+    tol = 0 if OPJ[name + ".lossless"][0] else 1
+    assert np.abs(planes[0].reshape(pix.shape).astype(np.int64) - pix.astype(np.int64)).max() <= tol
+
+
+def test_part1_and_ht_frames_in_one_batch(dec, orc):
+    """HT and Part-1 blocks share a job: the HT kernels take the front of the block table, k_mq_decode the rest"""
+    names = ["p1_rgb_mct", "rgb_mct", "p1_bypass_termall", "gray_3passes", "p1_gray_cb4x1024", "p1_97", "yuv422p12_97",
+             "p1_all_switches", "p1_truncated_2"]
+    pkts = [streams.get(n)[0] for n in names]
+    job = dec.job().parse_batch(pkts).upload().run().wait()
+    assert job.block_errors() == 0
+    for f, name in enumerate(names):
+        info_o, planes_o, _ = orc.decode(pkts[f])
+        info, planes = job.download_frame(f)
+        assert (info.width, info.height, info.pix_fmt) == (info_o.width, info_o.height, info_o.pix_fmt), name
+        for a, b in zip(planes, planes_o):
+            assert np.array_equal(a, b), name
+    job.free()
+
+
+@pytest.mark.parametrize("name", ["p1_gray_cb32", "p1_bypass_termall", "p1_all_switches", "p1_rgb_mct"])
+def test_part1_corrupt_bodies_match_oracle(dec, orc, name):
+    """the MQ decoder is total: on damaged code bytes (spurious markers, broken terminations, invalid bit-plane
+    counts) it still produces samples, and the reference dequantises whatever decode_cblk() left behind
+    (jpeg2000dec.c:2275-2290).  The device path must leave exactly the same pixels and error count."""
+    import ffmpeg_ht_amd as m
+    data, _ = streams.get(name)
+    rng = np.random.default_rng(len(name))
+    compared = 0
+    for _ in range(12):
+        bad = bytearray(data)
+        for pos in rng.integers(200, len(bad) - 2, 10):
+            bad[pos] = int(rng.integers(0, 256)) if rng.integers(0, 2) else 0xFF
+        try:
+            info_o, planes_o, _ = orc.decode(bytes(bad))
+        except oracle.DecodeError as e:
+            with pytest.raises(m.Htj2kError):
+                dec.decode(bytes(bad))
+            continue
+        info, planes, _, st = dec.decode(bytes(bad))
+        assert st.n_block_errors == orc.block_errors()
+        for a, b in zip(planes, planes_o):
+            assert np.array_equal(a, b)
+        compared += 1
+    assert compared > 0
+
+
+def test_part1_blocks_wider_than_64_are_refused(dec, orc):
+    """k_mq_decode keeps a block row in one 64-bit mask; wider Part-1 blocks are a documented PATCHWELCOME"""
+    import ffmpeg_ht_amd as m
+    data = vecgen.encode(streams._img(300, 90, 1, 8, 13), cb=(8, 4), nlevels=3, part1=True)
+    orc.decode(data)
+    with pytest.raises(m.Htj2kError) as e:
+        dec.decode(data)
+    assert e.value.code == -0x45574150                           # AVERROR_PATCHWELCOME
+
+
 def test_linesize_padding_is_respected(dec, orc):
     data, _ = streams.get("rgb_mct")
     info_o, planes_o, _ = orc.decode(data)

@@ -27,7 +27,8 @@ def test_parser_survives_mutations_under_asan_ubsan(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     files = []
     for name in ["gray_l5_cb64", "rgb_mct", "rgb_tiles_offsets", "rgb_cprl_prec", "gray_sop_eph", "yuv420p8",
-                 "gray_3passes", "placeholder_2_3p", "tiny_3x1_l2", "psot_zero"]:
+                 "gray_3passes", "placeholder_2_3p", "tiny_3x1_l2", "psot_zero",
+                 "p1_gray_cb32", "p1_bypass_termall", "p1_all_switches", "p1_rgb_tiles"]:
         f = tmp_path / (name + ".j2c")
         f.write_bytes(streams.get(name)[0])
         files.append(str(f))
