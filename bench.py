@@ -107,6 +107,39 @@ def cpu_baseline(streams, budget_s=12.0):
                       "oracle/j2k_oracle.c (C restatement of the reference decoder incl. host parsing)" % (n, el)}
 
 
+def part1_leg(dec, nframes, with_cpu):
+    """the bench's 4K RGB frames coded with Part-1 (MQ) codeblocks, default mode switches, device-resident like `value`"""
+    import ffmpeg_ht_amd
+    import vecgen
+    srcs = [vecgen.encode(vecgen.synth_image(WIDTH, HEIGHT, NCOMP, depth=8, seed=2 + i, noise=8), mct=1, nlevels=NLEVELS,
+                          cb=CB, transform=1, part1=True) for i in range(2)]
+    pk = [ffmpeg_ht_amd.packet(d) for d in srcs]
+    job = dec.job()
+    job.parse_batch([pk[i % 2] for i in range(nframes)]).upload().run().wait()
+    nblocks = job.num_blocks()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.run()
+    job.wait()
+    dt = (time.perf_counter() - t0) / steps
+    ht_ms = job.stage_ms()[0]
+    job.free()
+    out = {"Mpixel_s": round(nframes * WIDTH * HEIGHT / dt / 1e6, 1), "frames_per_step": nframes,
+           "ms_per_step": round(dt * 1e3, 2), "k_mq_decode_ms": round(ht_ms, 2),
+           "codeblocks_per_s": round(nblocks / dt), "code_MB_per_s": round(sum(len(srcs[i % 2]) for i in range(nframes)) / dt / 1e6, 1),
+           "workload": "configs[1] geometry with Part-1 blocks: 3840x2160 RGB 8-bit lossless 5/3 + RCT, 64x64, 5 levels, "
+                       "one quality layer, no mode switches"}
+    if with_cpu:
+        import oracle
+        orc = oracle.OracleDecoder()
+        t0 = time.perf_counter()
+        orc.decode(srcs[0])
+        out["cpu_oracle_Mpixel_s_1core"] = round(WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6, 2)
+        orc.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +150,9 @@ def main():
                     "latency-bound VLC kernel of one job overlaps the bandwidth-bound kernels of the other")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank (cycled to fill the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--part1", type=int, default=0, metavar="FRAMES",
+                    help="also time the same 4K frames coded with Part-1 (MQ) blocks: FRAMES per step through k_mq_decode "
+                         "(rank 0, reported as the extra object \"part1\"; SURVEY 8f rank 3, not part of `value`)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the three single-frame htj2k_decode() calls after the "
                     "timed region (profiling runs: every kernel launch in the trace is then a batch launch)")
     args = ap.parse_args()
@@ -307,6 +343,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(streams)
+        if args.part1 > 0:
+            res["part1"] = part1_leg(dec, args.part1, not args.no_cpu_baseline)
         print(json.dumps(res), flush=True)
     for job in jobs:
         job.free()

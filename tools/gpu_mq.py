@@ -53,3 +53,16 @@ if os.environ.get("TIMING", "1") == "1":
     dt = (time.perf_counter() - t0) / 3
     ms = job.stage_ms()
     print("batch %d: %.2f ms/step  %.1f Mpixel/s  stages %s" % (nb, dt * 1e3, nb * 3840 * 2160 / dt / 1e6, ms), flush=True)
+    if os.environ.get("SWEEP", "0") == "1":
+        for nb2 in (16, 48):
+            job.parse_batch([data] * nb2); job.upload(); job.run(); job.wait()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                job.run()
+            job.wait()
+            dt = (time.perf_counter() - t0) / 3
+            print("batch %d: %.2f ms/step  %.1f Mpixel/s  stages %s" % (nb2, dt * 1e3, nb2 * 3840 * 2160 / dt / 1e6, job.stage_ms()), flush=True)
+        t0 = time.perf_counter()
+        orc.decode(data)
+        dt = time.perf_counter() - t0
+        print("oracle (1 core): %.1f Mpixel/s" % (3840 * 2160 / dt / 1e6), flush=True)
