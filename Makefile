@@ -34,7 +34,10 @@ $(CSRC)/htj2k_device.o: $(CSRC)/htj2k_device.hip $(CSRC)/j2k_plan.h $(CSRC)/ht_c
 $(CSRC)/htj2k_pipe.o: $(CSRC)/htj2k_pipe.cpp include/htj2k_amd.h
 	$(CXX) -O2 -g -fPIC -std=c++17 -Wall -pthread -c $< -o $@
 
-$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o
+$(CSRC)/j2k_split.o: $(CSRC)/j2k_split.c include/htj2k_amd.h
+	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
+
+$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o $(CSRC)/j2k_split.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 # The oracle links the same host parser object as the product (parsing is not on the

@@ -79,7 +79,8 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
-           "htj2k_pipe_receive_device", "htj2k_job_device_frame"]
+           "htj2k_pipe_receive_device", "htj2k_job_device_frame",
+           "htj2k_splitter_open", "htj2k_splitter_find_end", "htj2k_splitter_parse", "htj2k_splitter_close"]
 
 _lib = None
 
@@ -246,6 +247,57 @@ def planes_to_arrays(info, planes):
 
 
 EAGAIN = -11
+
+
+class Splitter:
+    """htj2k_splitter_*: cuts a byte stream of back-to-back codestreams / JP2 files into packets (the reference's
+    jpeg2000 AVCodecParser, libavcodec/jpeg2000_parser.c).  Host only: works without a GPU."""
+    END_NOT_FOUND = -100
+
+    def __init__(self):
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        _check(self.L.htj2k_splitter_open(ctypes.byref(self.h)), "htj2k_splitter_open")
+
+    def find_end(self, data):
+        buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        return self.L.htj2k_splitter_find_end(self.h, buf, len(data))
+
+    def parse(self, data):
+        """-> (bytes consumed, frame bytes or None)"""
+        buf = (ctypes.c_uint8 * (len(data) + 64)).from_buffer_copy(bytes(data) + bytes(64))
+        fr, n = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_int()
+        used = _check(self.L.htj2k_splitter_parse(self.h, buf, len(data), ctypes.byref(fr), ctypes.byref(n)), "htj2k_splitter_parse")
+        return used, (ctypes.string_at(fr, n.value) if fr else None)
+
+    def split(self, stream, chunk=4096):
+        """all frames of `stream`, fed `chunk` bytes at a time (the av_parser_parse2 loop)"""
+        out, pos = [], 0
+        while pos < len(stream):
+            piece = stream[pos:pos + chunk]
+            while True:
+                used, fr = self.parse(piece)
+                if fr is not None:
+                    out.append(fr)
+                pos += used
+                piece = piece[used:]
+                if not piece or (used == 0 and fr is None):
+                    break
+        used, fr = self.parse(b"")
+        if fr:
+            out.append(fr)
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.htj2k_splitter_close(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Pipe:

@@ -241,6 +241,25 @@ int  htj2k_pipe_receive_device(htj2k_pipe *pipe, htj2k_frame *out);
 int  htj2k_pipe_skip(htj2k_pipe *pipe);
 void htj2k_pipe_close(htj2k_pipe *pipe);
 
+/* ---- framing: cutting a byte stream of back-to-back frames into packets ----------------------------
+ * The reference's AVCodecParser for this codec, `ff_jpeg2000_parser` (libavcodec/jpeg2000_parser.c:213-218,
+ * used by av_parser_parse2() for raw .j2k / .jp2 sequences and image pipes).  No device involved.
+ *   htj2k_splitter_find_end  = find_frame_end() (jpeg2000_parser.c:92-184): scans `size` more bytes and returns
+ *                              the offset, relative to `buf`, of the first byte of the NEXT frame -- negative
+ *                              (down to -11) when that byte arrived with an earlier call -- or
+ *                              HTJ2K_SPLIT_END_NOT_FOUND.
+ *   htj2k_splitter_parse     = jpeg2000_parse() + ff_combine_frame() (jpeg2000_parser.c:186-211,
+ *                              parser.c:203-288): returns the number of bytes of `buf` consumed; when a frame is
+ *                              complete *frame / *frame_size describe it (valid until the next call, followed by
+ *                              zeroed input padding unless it points into `buf`), else they are NULL / 0.
+ *                              Call with size 0 at the end of the input to flush the last frame. */
+#define HTJ2K_SPLIT_END_NOT_FOUND (-100)      /* END_NOT_FOUND, libavcodec/parser.h:40 */
+typedef struct htj2k_splitter htj2k_splitter;
+int  htj2k_splitter_open(htj2k_splitter **sp);
+int  htj2k_splitter_find_end(htj2k_splitter *sp, const uint8_t *buf, int size);
+int  htj2k_splitter_parse(htj2k_splitter *sp, const uint8_t *buf, int size, const uint8_t **frame, int *frame_size);
+void htj2k_splitter_close(htj2k_splitter *sp);
+
 const char *htj2k_version(void);
 /* name of the device the context is bound to, e.g. "gfx950" */
 const char *htj2k_device_name(htj2k_ctx *ctx);

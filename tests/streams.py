@@ -94,6 +94,12 @@ CASES = {
     "p1_noise_max":       (lambda: vecgen.encode([np.random.default_rng(2).integers(0, 256, (130, 130))], nlevels=3, part1=True), {}),
     "p1_all_zero":        (lambda: vecgen.encode([np.full((100, 100), 128)], nlevels=3, part1=True), {}),
     "p1_tiny_3x1":        (lambda: vecgen.encode([np.array([[77, 3, 250]])], nlevels=2, part1=True), {}),
+    # --- MIXED (SPcod bits 6-7 = 3): HT and Part-1 blocks in one stream, told apart in the packet header
+    #     (jpeg2000dec.c:1256-1340).  OpenJPEG does not read MIXED streams: restatement + own round trip only ---
+    "mixed_gray":         (lambda: _enc((200, 150, 1, 8, 3), mixed=True), {}),
+    "mixed_rgb_cb32":     (lambda: _enc((190, 131, 3, 8, 5), mct=1, mixed=True, cb=(5, 5), nlevels=3), {}),
+    "mixed_3passes_vsc":  (lambda: _enc((200, 150, 1, 8, 3), mixed=True, passes=3, vsc=True), {}),
+    "mixed_gray16_tiles": (lambda: _enc((160, 120, 1, 16, 8, 400), depth=16, nlevels=3, mixed=True, tile=(96, 64)), {}),
 }
 
 

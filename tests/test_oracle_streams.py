@@ -23,7 +23,7 @@ def test_oracle_decodes(orc, name):
     data, kw = streams.get(name)
     info, planes, consumed = orc.decode(data, **kw)
     assert orc.block_errors() == 0
-    assert consumed > 0 and info.is_ht == (0 if name.startswith("p1_") else 1)     # p1_*: Part-1 streams, no CAP marker
+    assert consumed > 0 and info.is_ht == (0 if name.startswith("p1_") else 1)     # p1_*: Part-1 streams, no CAP marker (MIXED ones have it)
     assert len(planes) == info.nplanes
 
 

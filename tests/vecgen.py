@@ -18,7 +18,8 @@ class EncParams(ctypes.Structure):
         + [("prec_w_log2", ctypes.c_int * 34), ("prec_h_log2", ctypes.c_int * 34), ("qstep", ctypes.c_double)]
         + [(n, ctypes.c_int) for n in ("expn_bias", "passes", "placeholder_sets", "cblk_style", "sop", "eph", "force_include",
                                        "never_empty_packets", "psot_zero", "rsiz", "cap_extra_bits")]
-        + [("comment", ctypes.c_char_p), ("part1", ctypes.c_int), ("p1_drop_passes", ctypes.c_int)]
+        + [("comment", ctypes.c_char_p), ("part1", ctypes.c_int), ("p1_drop_passes", ctypes.c_int),
+           ("mixed", ctypes.c_int)]
     )
 
 
@@ -40,7 +41,7 @@ def encode(comps, depth=8, sgnd=False, dx=None, dy=None, nlevels=5, cb=(6, 6), t
            guard_bits=0, prog=0, prec=None, qstep=1.0 / 32, expn_bias=0, passes=1, placeholder_sets=0,
            vsc=False, sop=False, eph=False, force_include=False, never_empty_packets=False, psot_zero=False,
            tile=(0, 0), offset=(0, 0), tile_offset=(0, 0), rsiz=0, cap_extra_bits=0, width=None, height=None,
-           comment=None, part1=False, cblk_style=None, drop_passes=0):
+           comment=None, part1=False, cblk_style=None, drop_passes=0, mixed=False):
     """comps: list of 2-D integer arrays (one per component, already subsampled).  Returns bytes."""
     if isinstance(comps, np.ndarray):
         comps = [comps] if comps.ndim == 2 else [comps[..., i] for i in range(comps.shape[-1])]
@@ -80,6 +81,7 @@ def encode(comps, depth=8, sgnd=False, dx=None, dy=None, nlevels=5, cb=(6, 6), t
     p.cblk_style = (0x08 if vsc else 0) if cblk_style is None else cblk_style
     p.part1 = int(part1)
     p.p1_drop_passes = drop_passes
+    p.mixed = int(mixed)
     p.sop, p.eph = int(sop), int(eph)
     p.force_include = int(force_include)
     p.never_empty_packets = int(never_empty_packets)

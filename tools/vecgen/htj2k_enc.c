@@ -921,6 +921,7 @@ typedef struct ECblk {
     int included;
     /* Part-1 blocks: magnitude bit-planes coded and the codeword segments in signalling order */
     int kbits, nseg, seglen[P1_MAX_SEGS], segpasses[P1_MAX_SEGS];
+    int is_p1;                 /* MIXED streams decide per block */
 } ECblk;
 typedef struct EPrec { int ncw, nch; ECblk *cb; TagTree incl, zbp; } EPrec;
 typedef struct EBand { int x0, x1, y0, y1; int xob, yob; int cbw, cbh; float fstep; int expn, mant, M_b; EPrec *prec; int offx, offy; } EBand;
@@ -973,8 +974,10 @@ static int encode_block(const htj2k_enc_params *P, const EBand *bd, ECblk *cb,
             any_full |= m != 0;
         }
     cb->included = 0; cb->npasses = 0; cb->lcup = cb->lref = 0;
-    if (P->part1) {
-        ret = p1_encode_block(full, sgn, w, h, bd->xob + 2 * bd->yob, P->cblk_style & 0x3F, P->p1_drop_passes,
+    /* MIXED (T.814 bits 6-7 of SPcod = 3): HT and Part-1 blocks side by side, here in a checkerboard */
+    cb->is_p1 = P->part1 || (P->mixed && (((cb->x0 >> bd->cbw) + (cb->y0 >> bd->cbh) + bd->xob) & 1));
+    if (cb->is_p1) {
+        ret = p1_encode_block(full, sgn, w, h, bd->xob + 2 * bd->yob, P->cblk_style & (P->mixed ? 0x08 : 0x3F), P->p1_drop_passes,
                               &cb->data, &cb->kbits, &cb->npasses, &cb->nseg, cb->seglen, cb->segpasses);
         cb->included = !ret && any_full;
         if (cb->kbits > *need_Mb) *need_Mb = cb->kbits;
@@ -1047,8 +1050,10 @@ static void write_packet(const htj2k_enc_params *P, ERes *rs, int precno, Buf *o
             else if (np <= 5) { bw_bits(&bw, 3, 2); bw_bits(&bw, (uint32_t)(np - 3), 2); }
             else if (np <= 36) { bw_bits(&bw, 0xF, 4); bw_bits(&bw, (uint32_t)(np - 6), 5); }
             else { bw_bits(&bw, 0x1FF, 9); bw_bits(&bw, (uint32_t)(np - 37), 7); }
-            if (P->part1) {
-                /* T.800 B.10.7: one length per codeword segment, lblock + floor(log2(passes in it)) bits */
+            if (cb->is_p1) {
+                /* T.800 B.10.7: one length per codeword segment, lblock + floor(log2(passes in it)) bits.
+                 * (In a MIXED stream the decoder tells such a block from an HT one by Lblock == 3 or a set
+                 * top bit of the first length field: the smallest sufficient Lblock gives exactly that.) */
                 int sg;
                 need = 0;
                 for (sg = 0; sg < cb->nseg; sg++)
@@ -1067,6 +1072,8 @@ static void write_packet(const htj2k_enc_params *P, ERes *rs, int precno, Buf *o
                 int b1 = 0, b2 = (z == 3) ? 1 : 0;
                 while ((2 << b1) <= seg1) b1++;
                 need = imax(bitlen32((uint32_t)cb->lcup) - b1, z > 1 ? bitlen32((uint32_t)cb->lref) - b2 : 0);
+                if (P->mixed)       /* HT block of a MIXED stream: Lblock > 3 and a clear top bit in the cleanup length */
+                    need = imax(4, imax(need, bitlen32((uint32_t)cb->lcup) - b1 + 1));
                 extra = imax(0, need - lblock);
                 for (; extra > 0; extra--) { bw_bit(&bw, 1); lblock++; }
                 bw_bit(&bw, 0);
@@ -1310,7 +1317,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
                         for (k = 0; k < pr->ncw * pr->nch; k++) {
                             ECblk *cb = &pr->cb[k];
                             int pp = P->passes > 1 ? 1 : 0;
-                            cb->zbp = P->part1 ? bd->M_b - cb->kbits : bd->M_b - 1 - pp - P->placeholder_sets;
+                            cb->zbp = cb->is_p1 ? bd->M_b - cb->kbits : bd->M_b - 1 - pp - P->placeholder_sets;
                             tt_set(&pr->incl, k, cb->included ? 0 : 1);
                             if (cb->included) tt_set(&pr->zbp, k, imax(cb->zbp, 0));
                             if (cb->included && cb->zbp < 0) ret = -5;
@@ -1412,7 +1419,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
         buf_u8(&out, P->dy[c] ? P->dy[c] : 1);
     }
     /* CAP: Part 15; Ccap15 bit 5 = HTIRV when 9/7 is used; MAGB field from the largest M_b */
-    if (!P->part1) {
+    if (!P->part1 || P->mixed) {
         int maxMb = 1, Pm;
         for (c = 0; c < P->ncomp; c++)
             for (r = 0; r < 3 * NL + 1; r++)
@@ -1420,7 +1427,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
         Pm = maxMb <= 8 ? 0 : (maxMb < 28 ? maxMb - 8 : 13 + (maxMb >> 2));
         if (Pm > 31) Pm = 31;
         buf_u16(&out, 0xFF50); buf_u16(&out, 8); buf_u32(&out, 0x00020000);
-        buf_u16(&out, (unsigned)((P->transform == 0 ? 0x20 : 0) | (Pm & 0x1F) | (P->cap_extra_bits & 0xF800)));
+        buf_u16(&out, (unsigned)((P->transform == 0 ? 0x20 : 0) | (Pm & 0x1F) | (P->cap_extra_bits & 0xF800) | (P->mixed ? 0xC000 : 0)));
     }
     buf_u16(&out, 0xFF52); buf_u16(&out, 12 + (P->nprec ? nres : 0));
     buf_u8(&out, (P->nprec ? 1 : 0) | (P->sop ? 2 : 0) | (P->eph ? 4 : 0));
@@ -1429,7 +1436,7 @@ int htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint8
     buf_u8(&out, P->mct ? 1 : 0);
     buf_u8(&out, NL);
     buf_u8(&out, P->cb_w_log2 - 2); buf_u8(&out, P->cb_h_log2 - 2);
-    buf_u8(&out, P->part1 ? (P->cblk_style & 0x3F) : (0x40 | (P->cblk_style & 0x08)));
+    buf_u8(&out, P->mixed ? (0xC0 | (P->cblk_style & 0x08)) : P->part1 ? (P->cblk_style & 0x3F) : (0x40 | (P->cblk_style & 0x08)));
     buf_u8(&out, P->transform);
     if (P->nprec)
         for (r = 0; r < nres; r++)

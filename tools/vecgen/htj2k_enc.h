@@ -37,6 +37,8 @@ typedef struct htj2k_enc_params {
     int part1;                  /* 1: Part-1 (MQ-coded) blocks, no CAP marker; cblk_style then honours BYPASS 0x01,
                                  * RESET 0x02, TERMALL 0x04, VSC 0x08, SEGSYM 0x20 */
     int p1_drop_passes;         /* Part-1: leave out the last N coding passes of every block (lossy truncation) */
+    int mixed;                  /* 1: MIXED stream (SPcod bits 6-7 = 3, Ccap15 bits 14-15 = 3): HT and Part-1 blocks in a
+                                 * checkerboard; of cblk_style only VSC is honoured */
 } htj2k_enc_params;
 
 /* comps[c]: int32 samples of component c, row-major, ceil(X1/dx)-ceil(X0/dx) wide.
