@@ -376,7 +376,7 @@ def test_openjpeg_encoded_part1_streams(dec, orc, name):
 def test_part1_and_ht_frames_in_one_batch(dec, orc):
     """HT and Part-1 blocks share a job: the HT kernels take the front of the block table, k_mq_decode the rest"""
     names = ["p1_rgb_mct", "rgb_mct", "p1_bypass_termall", "gray_3passes", "p1_gray_cb4x1024", "p1_97", "yuv422p12_97",
-             "p1_all_switches", "p1_truncated_2"]
+             "p1_all_switches", "p1_truncated_2", "mixed_3passes_vsc", "mixed_rgb_cb32"]
     pkts = [streams.get(n)[0] for n in names]
     job = dec.job().parse_batch(pkts).upload().run().wait()
     assert job.block_errors() == 0
