@@ -129,6 +129,7 @@ struct htj2k_job {
     int nht = 0;
     std::vector<MqWave> mqwaves;       /* one per 64 Part-1 blocks */
     size_t mq_scratch_units = 0;       /* 512-byte row slots of k_mq_decode's scratch */
+    uint32_t mq_planes = 1;            /* most bit-planes of a Part-1 block: sizes the LDS of k_mq_decode */
     DevBuf d_mqwaves, d_mqscratch;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
@@ -807,6 +808,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
                 return a.npasses > b.npasses;
             });
             j->mqwaves.clear();
+            j->mq_planes = 1;
             size_t units = 0;
             for (size_t i = (size_t)j->nht; i < j->blocks.size(); i += 64) {
                 MqWave W;
@@ -824,6 +826,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
                 if (units > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
                 W.soff = (uint32_t)units;
                 units += (size_t)(4 + std::min((pmax + 1) / 3 + 1, 32)) * W.rows;
+                j->mq_planes = std::max<uint32_t>(j->mq_planes, (uint32_t)std::min((pmax + 1) / 3 + 1, 32));
                 j->mqwaves.push_back(W);
             }
             j->mq_scratch_units = units;
@@ -1044,10 +1047,11 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
         if (nall) HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nall * sizeof(int), j->stream));
         if (nall > nblocks) {
-            hipLaunchKernelGGL(k_mq_decode, dim3((unsigned)j->mqwaves.size()), dim3(64), MQ_LDS_BYTES, j->stream,
+            const uint32_t area = mq_lds_area(j->mq_planes);
+            hipLaunchKernelGGL(k_mq_decode, dim3((unsigned)j->mqwaves.size()), dim3(64), area + MQ_LDS_TABLES, j->stream,
                                (const J2kBlock *)j->d_blocks.p + nblocks, nall - nblocks, (const uint8_t *)j->d_bytes.p,
                                (uint32_t *)j->d_coef.p, (int *)j->d_status.p + nblocks, (const MqWave *)j->d_mqwaves.p,
-                               (uint64_t *)j->d_mqscratch.p);
+                               (uint64_t *)j->d_mqscratch.p, area);
             HIP_TRY(c, hipGetLastError());
         }
         if (nblocks) {

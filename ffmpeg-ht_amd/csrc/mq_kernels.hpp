@@ -39,12 +39,19 @@ struct MqWave {                 /* one wave = up to 64 consecutive blocks of the
     uint16_t rows;              /* row slots per plane: round4(hmax) + 2 */
 };
 
-#define MQ_WIN_BYTES   128
-#define MQ_WIN_PITCH   33       /* dwords per lane */
+#define MQ_WIN_BYTES   96
+#define MQ_WIN_PITCH   25       /* dwords per lane */
 #define MQ_WIN_MARGIN  40
 #define MQ_CX_UNI 17
 #define MQ_CX_RL  18
-#define MQ_LDS_BYTES (64 * MQ_WIN_PITCH * 4 + 19 * 64 + 94 * 4 + 256 * 4 + 256 + 64 * 32 * 8)
+/* LDS: [code-byte windows + context states | aliased by the plane rows of the final assembly] + look-up tables.
+ * mq_lds_area(planes) is the size of the first, shared part: what limits the waves per CU */
+#define MQ_LDS_TABLES (94 * 4 + 256 * 4 + 256)
+__host__ __device__ inline uint32_t mq_lds_area(uint32_t nplanes)
+{
+    const uint32_t decode = 64 * MQ_WIN_PITCH * 4 + 19 * 64, assemble = nplanes * 64 * 8;
+    return ((decode > assemble ? decode : assemble) + 15u) & ~15u;
+}
 
 /* T.800 Table C.2: Qe, next state after an MPS, after an LPS, MPS switch */
 __device__ static const uint16_t mq_rows[47][4] = {
@@ -116,18 +123,19 @@ struct MqLane {
 /*
  * One lane per codeblock.  blocks: the Part-1 table (first block of wave g at waves[g] order: 64 * g).
  */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)
 k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, int *__restrict__ status, const MqWave *__restrict__ waves,
-            uint64_t *__restrict__ scratch)
+            uint64_t *__restrict__ scratch, uint32_t lds_area)
 {
     extern __shared__ __align__(16) uint8_t mq_lds[];
     uint32_t *win    = (uint32_t *)mq_lds;                          /* [64][MQ_WIN_PITCH] */
     uint8_t  *cx     = mq_lds + 64 * MQ_WIN_PITCH * 4;              /* [19][64] */
-    uint32_t *mqtab  = (uint32_t *)(cx + 19 * 64);                  /* [94]: qe | nmps << 16 | nlps << 24 */
+    uint64_t *vrow   = (uint64_t *)mq_lds;                          /* [planes][64]: the planes of one row, final assembly
+                                                                     * (the windows and contexts are dead by then) */
+    uint32_t *mqtab  = (uint32_t *)(mq_lds + lds_area);             /* [94]: qe | nmps << 16 | nlps << 24 */
     uint32_t *siglut = mqtab + 94;                                  /* [256]: one byte per bandpos */
     uint8_t  *sgnlut = (uint8_t *)(siglut + 256);                   /* [256]: label | xorbit << 7 */
-    uint64_t *vrow   = (uint64_t *)(sgnlut + 256);                  /* [32][64]: the planes of one row, final assembly */
 
     const int lane = threadIdx.x;
     const MqWave W = waves[blockIdx.x];
@@ -397,6 +405,7 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     fscale /= (float)(1 << (31 - M_b));
     const int transform = b.flags & 3, roi_shift = err ? 0 : b.roi_shift;
     uint32_t *dst = coef + b.plane_off;
+    __syncthreads();                                                 /* vrow takes over the window / context area */
     for (int y = 0; y < hmax; y++) {
         const uint64_t sgr = S[(size_t)(0 * R + y + 1) << 6], snr = S[(size_t)(1 * R + y + 1) << 6];
         __builtin_amdgcn_wave_barrier();

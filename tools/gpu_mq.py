@@ -54,7 +54,7 @@ if os.environ.get("TIMING", "1") == "1":
     ms = job.stage_ms()
     print("batch %d: %.2f ms/step  %.1f Mpixel/s  stages %s" % (nb, dt * 1e3, nb * 3840 * 2160 / dt / 1e6, ms), flush=True)
     if os.environ.get("SWEEP", "0") == "1":
-        for nb2 in (16, 48):
+        for nb2 in [int(v) for v in os.environ.get("SWEEP_BATCHES", "16,48").split(",")]:
             job.parse_batch([data] * nb2); job.upload(); job.run(); job.wait()
             t0 = time.perf_counter()
             for _ in range(3):
