@@ -803,6 +803,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             auto mid = std::stable_partition(j->blocks.begin(), j->blocks.end(), [&](const J2kBlock &b) { return !part1(b); });
             j->nht = (int)(mid - j->blocks.begin());
             std::stable_sort(mid, j->blocks.end(), [&](const J2kBlock &a, const J2kBlock &b) {
+                if ((a.w > 64) != (b.w > 64)) return a.w > 64;     /* the waves that need k_mq_decode<true> come first */
                 if (a.h != b.h) return a.h > b.h;
                 if (a.w != b.w) return a.w > b.w;
                 return a.npasses > b.npasses;
@@ -815,17 +816,15 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
                 int hmax = 0, wmax = 0, pmax = 0;
                 for (size_t k = i; k < std::min(i + 64, j->blocks.size()); k++) {
                     const J2kBlock &b = j->blocks[k];
-                    if (b.w > 64) {
-                        clog(c, 16, "Part-1 codeblock wider than 64 columns (%d x %d): not handled by the HIP path\n", b.w, b.h);
-                        return HTJ2K_ERR_PATCHWELCOME;
-                    }
                     hmax = std::max<int>(hmax, b.h); wmax = std::max<int>(wmax, b.w); pmax = std::max<int>(pmax, b.npasses);
                 }
                 W.hmax = (uint16_t)hmax; W.wmax = (uint16_t)wmax; W.pmax = (uint16_t)pmax;
                 W.rows = (uint16_t)(((hmax + 3) & ~3) + 2);
+                W.chunks = (uint16_t)((wmax + 63) / 64);
+                W.pad = 0;
                 if (units > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
                 W.soff = (uint32_t)units;
-                units += (size_t)(4 + std::min((pmax + 1) / 3 + 1, 32)) * W.rows;
+                units += (size_t)(4 + std::min((pmax + 1) / 3 + 1, 32)) * W.rows * W.chunks;
                 j->mq_planes = std::max<uint32_t>(j->mq_planes, (uint32_t)std::min((pmax + 1) / 3 + 1, 32));
                 j->mqwaves.push_back(W);
             }
@@ -1048,10 +1047,19 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         if (nall) HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nall * sizeof(int), j->stream));
         if (nall > nblocks) {
             const uint32_t area = mq_lds_area(j->mq_planes);
-            hipLaunchKernelGGL(k_mq_decode, dim3((unsigned)j->mqwaves.size()), dim3(64), area + MQ_LDS_TABLES, j->stream,
-                               (const J2kBlock *)j->d_blocks.p + nblocks, nall - nblocks, (const uint8_t *)j->d_bytes.p,
-                               (uint32_t *)j->d_coef.p, (int *)j->d_status.p + nblocks, (const MqWave *)j->d_mqwaves.p,
-                               (uint64_t *)j->d_mqscratch.p, area);
+            unsigned nwide = 0;                                      /* waves holding a block wider than 64 columns */
+            while (nwide < j->mqwaves.size() && j->mqwaves[nwide].chunks > 1) nwide++;
+            const unsigned nnarrow = (unsigned)j->mqwaves.size() - nwide;
+            if (nwide)
+                hipLaunchKernelGGL(k_mq_decode<true>, dim3(nwide), dim3(64), area + MQ_LDS_TABLES, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p + nblocks, nall - nblocks, (const uint8_t *)j->d_bytes.p,
+                                   (uint32_t *)j->d_coef.p, (int *)j->d_status.p + nblocks, (const MqWave *)j->d_mqwaves.p,
+                                   (uint64_t *)j->d_mqscratch.p, area);
+            if (nnarrow)
+                hipLaunchKernelGGL(k_mq_decode<false>, dim3(nnarrow), dim3(64), area + MQ_LDS_TABLES, j->stream,
+                                   (const J2kBlock *)j->d_blocks.p + nblocks + 64 * (size_t)nwide, nall - nblocks - 64 * (int)nwide,
+                                   (const uint8_t *)j->d_bytes.p, (uint32_t *)j->d_coef.p, (int *)j->d_status.p + nblocks + 64 * (size_t)nwide,
+                                   (const MqWave *)j->d_mqwaves.p + nwide, (uint64_t *)j->d_mqscratch.p, area);
             HIP_TRY(c, hipGetLastError());
         }
         if (nblocks) {

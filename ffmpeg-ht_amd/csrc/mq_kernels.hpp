@@ -13,7 +13,7 @@
  * 64 blocks per wave, all lanes walking the stripe-oriented scan in lockstep (the host groups blocks of equal
  * size).  What makes that affordable:
  *   - no per-sample flag words: significance, sign, "visited" and "refined" live as 64-bit ROW MASKS (block
- *     width <= 64), six rows of a stripe in registers; the eight neighbours of a sample are three 3-bit fields
+ *     chunk of <= 64 columns), six rows of a stripe in registers; the eight neighbours of a sample are three 3-bit fields
  *     of three row masks, and the column position is wave-uniform (scalar shifts);
  *   - no per-sample magnitudes either: every bit-plane k leaves one row mask per row ("bit k of the samples of
  *     this row"); the samples are assembled once, at the end, together with the half-bit the reference keeps
@@ -22,7 +22,8 @@
  *     is one 512-byte coalesced access;
  *   - each lane's code bytes come from a 128-byte LDS window refilled for the whole wave when the furthest lane
  *     gets within 40 bytes of its end (a decision consumes at most 3 bytes, a column at most 11 decisions).
- * Blocks wider than 64 columns (legal: up to 1024 x 4) are refused by the host layer for now.
+ * Rows wider than 64 columns (legal: up to 1024 x 4) are walked in 64-column chunks; the two columns next to a chunk
+ * come along as one border bit per row.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -37,6 +38,8 @@ struct MqWave {                 /* one wave = up to 64 consecutive blocks of the
     uint16_t hmax, wmax;        /* largest block of the wave */
     uint16_t pmax;              /* most coding passes */
     uint16_t rows;              /* row slots per plane: round4(hmax) + 2 */
+    uint16_t chunks;            /* 64-column chunks per row: ceil(wmax / 64) */
+    uint16_t pad;
 };
 
 #define MQ_WIN_BYTES   96
@@ -111,6 +114,11 @@ __device__ __forceinline__ uint32_t mq_g3(uint64_t m, int x)
 {
     return (x ? (uint32_t)(m >> (x - 1)) : (uint32_t)m << 1) & 7u;
 }
+/* the same for one 64-column chunk of a wider row: `lb` / `rb` are the bits of the columns just outside the chunk */
+__device__ __forceinline__ uint32_t mq_g3(uint64_t m, int x, uint32_t lb, uint32_t rb)
+{
+    return ((x ? (uint32_t)(m >> (x - 1)) : ((uint32_t)m << 1 | lb)) & 7u) | (x == 63 ? rb << 2 : 0u);
+}
 
 struct MqLane {
     uint32_t a, c;              /* mqc->a, mqc->c */
@@ -123,6 +131,7 @@ struct MqLane {
 /*
  * One lane per codeblock.  blocks: the Part-1 table (first block of wave g at waves[g] order: 64 * g).
  */
+template <bool WIDE>                                                 /* WIDE: some block of the launch has more than 64 columns */
 __global__ void __launch_bounds__(64, 4)
 k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, int *__restrict__ status, const MqWave *__restrict__ waves,
@@ -139,8 +148,9 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
 
     const int lane = threadIdx.x;
     const MqWave W = waves[blockIdx.x];
-    const int hmax = W.hmax, wmax = W.wmax, pmax = W.pmax, R = W.rows;
-    uint64_t *S = scratch + ((size_t)W.soff << 6) + lane;           /* row slot s of plane p: S[(p * R + s) << 6] */
+    const int hmax = W.hmax, wmax = W.wmax, pmax = W.pmax, R = W.rows, WC = WIDE ? W.chunks : 1;
+    uint64_t *S = scratch + ((size_t)W.soff << 6) + lane;           /* chunk c of row slot s of plane p: S[SL(p, s, c)] */
+#define SL(p, s, c) ((size_t)(((p) * R + (s)) * WC + (c)) << 6)
     const int bi = blockIdx.x * 64 + lane;
     const bool have = bi < nblocks;
 
@@ -180,7 +190,7 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     int err = 0, nexec = 0, term_cnt = 0;
 
     /* zero the state planes: significance, sign, visited, refined */
-    for (int s = 0; s < 4 * R; s++) S[(size_t)s << 6] = 0;
+    for (int s = 0; s < 4 * R * WC; s++) S[(size_t)s << 6] = 0;
 
     MqLane m;
     m.a = 0x8000; m.c = 0; m.bp = 0; m.cur = 0; m.wb = 0; m.raw = false;
@@ -267,35 +277,53 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
         }
         if (!__ballot(act)) break;
         if (act) nexec = i + 1;
-        uint64_t *Pv = S + ((size_t)(4 + k) * R << 6);               /* this bit-plane's value rows */
+        const int PV = 4 + k;                                        /* this bit-plane's value rows */
 
-        for (int y0 = 0; y0 < hmax; y0 += 4) {
+        for (int y0 = 0; y0 < hmax; y0 += 4)
+        for (int ch = 0; ch < WC; ch++) {                            /* rows wider than 64 columns: chunk by chunk */
             if (__ballot(act && m.bp + 1 + MQ_WIN_MARGIN > m.wb + MQ_WIN_BYTES)) refill();
             uint64_t sg[6], sn[6], vis[4], ref[4], val[4];
 #pragma unroll
-            for (int q = 0; q < 6; q++) { sg[q] = S[(size_t)(0 * R + y0 + q) << 6]; sn[q] = S[(size_t)(1 * R + y0 + q) << 6]; }
+            for (int q = 0; q < 6; q++) { sg[q] = S[SL(0, y0 + q, ch)]; sn[q] = S[SL(1, y0 + q, ch)]; }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                vis[q] = (type != 0 && k > 0) ? S[(size_t)(2 * R + y0 + 1 + q) << 6] : 0;
-                ref[q] = type == 1 ? S[(size_t)(3 * R + y0 + 1 + q) << 6] : 0;
-                val[q] = (type == 1 || (type == 2 && k > 0)) ? Pv[(size_t)(y0 + 1 + q) << 6] : 0;
+                vis[q] = (type != 0 && k > 0) ? S[SL(2, y0 + 1 + q, ch)] : 0;
+                ref[q] = type == 1 ? S[SL(3, y0 + 1 + q, ch)] : 0;
+                val[q] = (type == 1 || (type == 2 && k > 0)) ? S[SL(PV, y0 + 1 + q, ch)] : 0;
+            }
+            /* significance and sign of the columns next to the chunk, one bit per row (bit q = row y0 - 1 + q): the
+             * chunk on the left has been through this pass already, the one on the right has not */
+            uint32_t lbg = 0, rbg = 0, lbs = 0, rbs = 0;
+            if (WIDE && WC > 1) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    if (ch > 0)      { lbg |= (uint32_t)(S[SL(0, y0 + q, ch - 1)] >> 63) << q; lbs |= (uint32_t)(S[SL(1, y0 + q, ch - 1)] >> 63) << q; }
+                    if (ch + 1 < WC) { rbg |= ((uint32_t)S[SL(0, y0 + q, ch + 1)] & 1u) << q; rbs |= ((uint32_t)S[SL(1, y0 + q, ch + 1)] & 1u) << q; }
+                }
             }
             const bool full = y0 + 3 < h;
+            const int xw = min(64, wmax - 64 * ch);
 
-            for (int x = 0; x < wmax; x++) {
+            for (int x = 0; x < xw; x++) {
                 if (__ballot(act && m.bp + 1 + MQ_WIN_MARGIN > m.wb + MQ_WIN_BYTES)) refill();
                 const uint64_t bit = 1ull << x;
-                const bool inx = act && x < w;
+                const bool inx = act && 64 * ch + x < w;
                 auto field = [&](int r, uint32_t &n3, uint32_t &c3, uint32_t &s3) {
-                    n3 = mq_g3(sg[r], x); c3 = mq_g3(sg[r + 1], x);
-                    s3 = (vsc && r == 3) ? 0u : mq_g3(sg[r + 2], x);
+                    if (WIDE) {
+                        n3 = mq_g3(sg[r], x, (lbg >> r) & 1, (rbg >> r) & 1);
+                        c3 = mq_g3(sg[r + 1], x, (lbg >> (r + 1)) & 1, (rbg >> (r + 1)) & 1);
+                        s3 = (vsc && r == 3) ? 0u : mq_g3(sg[r + 2], x, (lbg >> (r + 2)) & 1, (rbg >> (r + 2)) & 1);
+                    } else {
+                        n3 = mq_g3(sg[r], x); c3 = mq_g3(sg[r + 1], x);
+                        s3 = (vsc && r == 3) ? 0u : mq_g3(sg[r + 2], x);
+                    }
                 };
                 /* decode the sign of (x, r) and make it significant (set_significance, jpeg2000.c:172-195) */
                 auto sign_and_set = [&](int r, bool on, bool always_xor) {
                     if (!__ballot(on)) return;
                     uint32_t n3, c3, s3;
                     field(r, n3, c3, s3);
-                    const uint32_t sc = mq_g3(sn[r + 1], x);
+                    const uint32_t sc = WIDE ? mq_g3(sn[r + 1], x, (lbs >> (r + 1)) & 1, (rbs >> (r + 1)) & 1) : mq_g3(sn[r + 1], x);
                     const uint32_t sN = (n3 >> 1) & 1, sS = (s3 >> 1) & 1, sW = c3 & 1, sE = (c3 >> 2) & 1;
                     const uint32_t J = sN | sS << 1 | sW << 2 | sE << 3 |
                                        (sN & (uint32_t)(sn[r] >> x)) << 4 | (sS & (uint32_t)(sn[r + 2] >> x) & 1) << 5 |
@@ -372,10 +400,10 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             /* rows of this stripe back to the planes */
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (type != 1) { S[(size_t)(0 * R + y0 + 1 + q) << 6] = sg[q + 1]; S[(size_t)(1 * R + y0 + 1 + q) << 6] = sn[q + 1]; }
-                if (type == 0) S[(size_t)(2 * R + y0 + 1 + q) << 6] = vis[q];
-                if (type == 1) S[(size_t)(3 * R + y0 + 1 + q) << 6] = ref[q];
-                Pv[(size_t)(y0 + 1 + q) << 6] = val[q];
+                if (type != 1) { S[SL(0, y0 + 1 + q, ch)] = sg[q + 1]; S[SL(1, y0 + 1 + q, ch)] = sn[q + 1]; }
+                if (type == 0) S[SL(2, y0 + 1 + q, ch)] = vis[q];
+                if (type == 1) S[SL(3, y0 + 1 + q, ch)] = ref[q];
+                S[SL(PV, y0 + 1 + q, ch)] = val[q];
             }
         }
         if (type == 2 && __ballot(act && (style & 0x20))) {          /* segmentation symbol: read, not checked (:1980-1990) */
@@ -406,15 +434,16 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     const int transform = b.flags & 3, roi_shift = err ? 0 : b.roi_shift;
     uint32_t *dst = coef + b.plane_off;
     __syncthreads();                                                 /* vrow takes over the window / context area */
-    for (int y = 0; y < hmax; y++) {
-        const uint64_t sgr = S[(size_t)(0 * R + y + 1) << 6], snr = S[(size_t)(1 * R + y + 1) << 6];
+    for (int y = 0; y < hmax; y++)
+    for (int ch = 0; ch < WC; ch++) {
+        const uint64_t sgr = S[SL(0, y + 1, ch)], snr = S[SL(1, y + 1, ch)];
         __builtin_amdgcn_wave_barrier();
         for (int k = 0; k < nplanes; k++)
-            vrow[k * 64 + lane] = k <= klast ? S[(size_t)((4 + k) * R + y + 1) << 6] : 0;
+            vrow[k * 64 + lane] = k <= klast ? S[SL(4 + k, y + 1, ch)] : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint64_t vl = klast >= 0 ? vrow[klast * 64 + lane] : 0;
-        for (int x = 0; x < wmax; x++) {
+        for (int x = 0; x < min(64, wmax - 64 * ch); x++) {
             uint32_t mag = 0;
             for (int k = 0; k < nplanes; k++) {
                 const uint32_t bitk = (uint32_t)(vrow[k * 64 + lane] >> x) & 1u;
@@ -425,11 +454,12 @@ k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                 mag |= 1u << ((bpno0 - kl) & 31);
             }
             const uint32_t smag = (mag & 0x7FFFFFFFu) | ((uint32_t)(snr >> x) & 1u) << 31;
-            if (have && x < w && y < h && npasses > 0)
-                dst[(size_t)y * b.stride + x] = ht_dequant(smag, transform, M_b, roi_shift, fscale, b.i_step);
+            if (have && 64 * ch + x < w && y < h && npasses > 0)
+                dst[(size_t)y * b.stride + 64 * ch + x] = ht_dequant(smag, transform, M_b, roi_shift, fscale, b.i_step);
         }
     }
     if (have && err) status[bi] = 1;
+#undef SL
 }
 
 }  // namespace htj2k

@@ -75,6 +75,9 @@ CASES = {
     "p1_gray_cb16x64":    (lambda: _enc((200, 150, 1, 8, 3), part1=True, cb=(4, 6), nlevels=3), {}),
     "p1_gray_cb64x4":     (lambda: _enc((200, 150, 1, 8, 3), part1=True, cb=(6, 2), nlevels=2), {}),
     "p1_gray_cb4x1024":   (lambda: _enc((40, 1100, 1, 8, 14), part1=True, cb=(2, 10), nlevels=2), {}),
+    "p1_gray_cb128x32":   (lambda: _enc((300, 90, 1, 8, 13), part1=True, cb=(7, 5), nlevels=2), {}),
+    "p1_cb256x16_modes":  (lambda: _enc((600, 70, 1, 12, 13, 60), depth=12, part1=True, cb=(8, 4), nlevels=1, cblk_style=0x29), {}),
+    "p1_gray_cb1024x4":   (lambda: _enc((1100, 40, 1, 8, 14), part1=True, cb=(10, 2), nlevels=1), {}),
     "p1_bypass":          (lambda: _enc((200, 150, 1, 12, 3, 60), depth=12, part1=True, cblk_style=0x01), {}),
     "p1_reset":           (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x02), {}),
     "p1_termall":         (lambda: _enc((200, 150, 1, 8, 3), part1=True, cblk_style=0x04), {}),

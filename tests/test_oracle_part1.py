@@ -32,6 +32,7 @@ LOSSLESS = {
     "p1_vsc": ((200, 150, 1, 8, 3), 8), "p1_segsym": ((200, 150, 1, 8, 3), 8), "p1_bypass_termall": ((200, 150, 1, 12, 3, 60), 12),
     "p1_all_switches": ((160, 120, 1, 16, 8, 400), 16), "p1_rgb_mct": ((190, 131, 3, 8, 5), 8),
     "p1_rgb_tiles": ((190, 131, 3, 8, 6), 8),
+    "p1_gray_cb128x32": ((300, 90, 1, 8, 13), 8), "p1_cb256x16_modes": ((600, 70, 1, 12, 13, 60), 12), "p1_gray_cb1024x4": ((1100, 40, 1, 8, 14), 8),
     "mixed_gray": ((200, 150, 1, 8, 3), 8), "mixed_rgb_cb32": ((190, 131, 3, 8, 5), 8), "mixed_gray16_tiles": ((160, 120, 1, 16, 8, 400), 16),
 }
 
