@@ -897,6 +897,11 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_bytes.p + F.bytes_base, F.plan->bytes, F.plan->nbytes,
                                       hipMemcpyHostToDevice, j->stream));
     }
+    for (int f = 0; f < j->nframes; f++) {                 /* PAL8: the palette is the second plane (jpeg2000dec.c:2900-2901) */
+        const FrameSlot &F = j->frames[f];
+        if (F.plan->info.has_palette && F.plan->info.nplanes > 1)
+            HIP_TRY(c, hipMemcpyAsync(F.out.ptr[1], F.plan->palette, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+    }
     if (nblocks) {
         HIP_TRY(c, hipMemcpyAsync(j->d_blocks.p, j->blocks.data(), (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice, j->stream));
         HIP_TRY(c, hipMemcpyAsync(j->d_qoff.p, j->qoff.data(), j->qoff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));

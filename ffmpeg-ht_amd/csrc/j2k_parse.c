@@ -2395,8 +2395,14 @@ static void fill_info(J2kParser *s, htj2k_info *info)
     info->is_ht = s->isHT;
     info->has_palette = s->pix_fmt == HTJ2K_PIX_PAL8;
     if (!d) return;
-    info->nplanes = d->pal ? 1 : d->nplanes;
+    info->nplanes = d->nplanes;
     for (p = 0; p < info->nplanes; p++) {
+        if (d->pal && p == 1) {                      /* AVFrame.data[1] of PAL8: 256 native-endian 0xAARRGGBB entries */
+            info->plane_width[p] = 256;
+            info->plane_height[p] = 1;
+            info->plane_bytes_per_sample[p] = 4;
+            continue;
+        }
         int cw = (p == 1 || p == 2) ? d->log2_chroma_w : 0;
         int ch = (p == 1 || p == 2) ? d->log2_chroma_h : 0;
         info->plane_width[p]  = d->planar ? -((-info->width)  >> cw) : info->width;
@@ -2683,10 +2689,6 @@ static int build_plan(J2kParser *s)
                                    s->pix_fmt == HTJ2K_PIX_RGBA64 || s->pix_fmt == HTJ2K_PIX_GRAY16) ? 16 : s->precision;
     }
     memcpy(pl->palette, s->palette, sizeof(pl->palette));
-    if (s->pix_fmt == HTJ2K_PIX_PAL8) {
-        plog(s, LOG_ERROR, "palettised JP2 output is not handled by the HIP HT path\n");
-        return HTJ2K_ERR_PATCHWELCOME;
-    }
     return 0;
 }
 

@@ -85,7 +85,7 @@ typedef struct htj2k_info {
     int plane_width[4];        /* in samples */
     int plane_height[4];
     int plane_bytes_per_sample[4]; /* bytes per sample * samples per pixel in that plane (row = this * plane_width) */
-    int has_palette;
+    int has_palette;           /* pal8 (JP2 pclr box): plane 1 is the palette, 256 native-endian 0xAARRGGBB entries (jpeg2000dec.c:2900-2901) */
 } htj2k_info;
 
 /* mirror of AVFrame.data/linesize (libavutil/frame.h:410,434): caller-owned system memory */

@@ -1007,6 +1007,8 @@ ORC_EXPORT int orc_frame_write(OrcFrame *f, htj2k_frame *out)
                     ((uint16_t *)(out->data[t->out_plane] + (size_t)py * out->linesize[t->out_plane]))[px * t->pix_step + t->pix_off] = (uint16_t)val;
             }
     }
+    if (pl->info.has_palette && out->data[1])        /* jpeg2000dec.c:2900-2901 */
+        memcpy(out->data[1], pl->palette, 256 * sizeof(uint32_t));
     out->width = pl->info.width;
     out->height = pl->info.height;
     out->pix_fmt = pl->info.pix_fmt;

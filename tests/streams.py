@@ -68,6 +68,10 @@ CASES = {
     "gray_97_offset":    (lambda: _enc((201, 149, 1, 8, 4), nlevels=3, offset=(3, 5), transform=0, qstep=1), {}),
     "gray_97_bitexact":  (lambda: _enc((200, 150, 1, 8, 3), transform=0, qstep=2), {"bitexact": 1}),
     "rgb_97_bitexact":   (lambda: _enc((190, 131, 3, 8, 5), transform=0, mct=1, qstep=1), {"bitexact": 1}),
+    # --- palettised JP2 (pclr + cmap boxes): pal8, the palette is AVFrame.data[1] (jpeg2000dec.c:2900-2901) ---
+    "pal8_jp2":           (lambda: vecgen.jp2_wrap(vecgen.encode([(np.add.outer(np.arange(40), np.arange(56)) * 3 % 200).astype(np.int32)], nlevels=2),
+                                                   56, 40, 1, 8, colourspace=16,
+                                                   palette=[((i * 7) & 255, (255 - i) & 255, (i * 3 + 1) & 255) for i in range(200)]), {}),
     # --- Part-1 (MQ-coded) blocks: decode_cblk() instead of the HT decoder; style bits BYPASS 1, RESET 2,
     #     TERMALL 4, VSC 8, SEGSYM 0x20 ---
     "p1_gray":            (lambda: _enc((200, 150, 1, 8, 3), part1=True), {}),

@@ -99,6 +99,19 @@ def test_jp2_wrapper_colourspace_and_sar(orc):
     assert oracle.PIX_NAMES[info2.pix_fmt] == "rgb48le"
 
 
+def test_palettised_jp2(orc):
+    """pclr / cmap boxes select pal8: plane 0 holds the indices, plane 1 the 256 x 0xAARRGGBB palette"""
+    data, kw = streams.get("pal8_jp2")
+    info, planes, _ = orc.decode(data)
+    assert oracle.PIX_NAMES[info.pix_fmt] == "pal8" and info.has_palette == 1 and info.nplanes == 2
+    assert np.array_equal(planes[0], (np.add.outer(np.arange(40), np.arange(56)) * 3 % 200))
+    pal = planes[1].reshape(-1).view("<u4")
+    assert pal.shape == (256,)
+    for i in (0, 1, 57, 199):
+        assert pal[i] == (0xFF << 24 | ((i * 7) & 255) << 16 | ((255 - i) & 255) << 8 | ((i * 3 + 1) & 255))
+    assert not pal[200:].any()
+
+
 def test_lowres_dimensions(orc):
     data, _ = streams.get("gray_l5_cb64")
     info = orc.probe(data, reduction_factor=2)

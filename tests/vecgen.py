@@ -118,7 +118,7 @@ def encode_block(vals, passes=1, causal=False):
     return data, lcup.value, lref.value, mu.value
 
 
-def jp2_wrap(codestream, width, height, ncomp, depth, colourspace=None, cdef=None, res=None):
+def jp2_wrap(codestream, width, height, ncomp, depth, colourspace=None, cdef=None, res=None, palette=None):
     """Minimal JP2 file around a codestream (jP signature, ftyp, jp2h{ihdr,colr[,cdef][,res ]}, jp2c)."""
     import struct
 
@@ -134,6 +134,13 @@ def jp2_wrap(codestream, width, height, ncomp, depth, colourspace=None, cdef=Non
         for cn, typ, asoc in cdef:
             payload += struct.pack(">HHH", cn, typ, asoc)
         inner += box(b"cdef", payload)
+    if palette is not None:
+        # pclr: NE entries, 3 columns of 8 bits; cmap: component 0 through palette columns 0..2
+        payload = struct.pack(">HBBBB", len(palette), 3, 7, 7, 7)
+        for r, g, b in palette:
+            payload += struct.pack(">BBB", r, g, b)
+        inner += box(b"pclr", payload)
+        inner += box(b"cmap", b"".join(struct.pack(">HBB", 0, 1, k) for k in range(3)))
     if res:
         vn, vd, hn, hd, ve, he = res
         inner += box(b"res ", box(b"resc", struct.pack(">HHHHBB", vn, vd, hn, hd, ve, he)))
