@@ -73,7 +73,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_upload", "htj2k_job_run", "htj2k_job_download", "htj2k_job_wait", "htj2k_job_info",
            "htj2k_job_bytes_consumed", "htj2k_job_free", "htj2k_job_num_tilecomps", "htj2k_job_tilecomp_dims",
            "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
-           "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_job_block_errors",
+           "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
            "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes",
@@ -449,6 +449,18 @@ class Decoder:
         _check(self.L.htj2k_mct_planes(self.h, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                        c.ctypes.data_as(ctypes.c_void_p), a.size, type_), "htj2k_mct_planes")
         return a, b, c
+
+    def mq_blocks(self, descs, pool, nsamples, dtype=np.int32):
+        """Part-1 blocks (BlockDesc.flags & 4, bytes + trailer as in j2k_plan.h) -> (samples[nsamples], status[n])"""
+        n = len(descs)
+        arr = (BlockDesc * n)(*descs)
+        buf = ctypes.create_string_buffer(bytes(pool) + b"\0" * 64, len(pool) + 64)
+        out = np.full(nsamples, 0x7FFFFFFF if dtype == np.int32 else np.nan, dtype=dtype)
+        status = np.zeros(n, dtype=np.int32)
+        _check(self.L.htj2k_mq_blocks(self.h, arr, n, buf, ctypes.c_size_t(len(pool) + 64),
+                                      out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nsamples),
+                                      status.ctypes.data_as(ctypes.c_void_p)), "htj2k_mq_blocks")
+        return out, status
 
     def ht_blocks(self, descs, pool, nsamples, dtype=np.int32):
         """descs: list of BlockDesc; pool: bytes.  -> (samples[nsamples], status[n])"""

@@ -1514,6 +1514,75 @@ extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int 
 
 /* HT block decoder alone: decode `n` codeblocks given as a descriptor table + byte pool into
  * a sample buffer (unit parity against ff_jpeg2000_decode_htj2k + dequantisation) */
+/* decode_cblk() + dequantisation on a caller-built table of Part-1 blocks: every descriptor carries J2K_BLK_PART1 and
+ * its bytes are laid out as j2k_parse.c does it (j2k_plan.h: segments, 0xFF 0xFF terminators, J2kPart1Trailer) */
+extern "C" int htj2k_mq_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks, const uint8_t *bytes_in, size_t nbytes_in,
+                               void *coef, size_t nsamples, int *status)
+{
+    if (!c || !blocks_in || nblocks <= 0 || !bytes_in || !coef) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<J2kBlock> blk((const J2kBlock *)blocks_in, (const J2kBlock *)blocks_in + nblocks);
+    std::vector<uint8_t> pool(16, 0);
+    for (int i = 0; i < nblocks; i++) {
+        J2kBlock &b = blk[i];
+        if (!(b.flags & J2K_BLK_PART1)) return HTJ2K_ERR_EINVAL;
+        const size_t len = J2K_P1_TRAILER_OFF(b.lcup) + 4 + 2 * (size_t)b.lref;
+        if ((size_t)b.data_off + len > nbytes_in) return HTJ2K_ERR_EINVAL;
+        const size_t o = pool.size();
+        pool.resize(o + J2K_P1_REGION(b.lcup, b.lref), 0);
+        memcpy(pool.data() + o, bytes_in + b.data_off, len);
+        b.data_off = (uint32_t)o;
+    }
+    pool.resize(pool.size() + 256, 0);
+    std::vector<MqWave> waves;
+    size_t units = 0;
+    uint32_t planes = 1;
+    bool wide = false;
+    for (int i = 0; i < nblocks; i += 64) {
+        MqWave W;
+        int hmax = 0, wmax = 0, pmax = 0;
+        for (int k = i; k < std::min(i + 64, nblocks); k++) {
+            hmax = std::max<int>(hmax, blk[k].h); wmax = std::max<int>(wmax, blk[k].w); pmax = std::max<int>(pmax, blk[k].npasses);
+        }
+        const int np = std::min((pmax + 1) / 3 + 1, 32);
+        W.hmax = (uint16_t)hmax; W.wmax = (uint16_t)wmax; W.pmax = (uint16_t)pmax;
+        W.rows = (uint16_t)(((hmax + 3) & ~3) + 2);
+        W.chunks = (uint16_t)((wmax + 63) / 64); W.pad = 0;
+        W.soff = (uint32_t)units;
+        units += (size_t)(4 + np) * W.rows * W.chunks;
+        planes = std::max<uint32_t>(planes, (uint32_t)np);
+        wide = wide || W.chunks > 1;
+        waves.push_back(W);
+    }
+    DevBuf db, dby, dc, ds, dw, dsc;
+    auto release_all = [&]() { db.release(); dby.release(); dc.release(); ds.release(); dw.release(); dsc.release(); };
+    int r;
+    if ((r = db.ensure((size_t)nblocks * sizeof(J2kBlock))) < 0 || (r = dby.ensure(pool.size())) < 0 ||
+        (r = dc.ensure(nsamples * 4 + 64)) < 0 || (r = ds.ensure((size_t)nblocks * 4)) < 0 ||
+        (r = dw.ensure(waves.size() * sizeof(MqWave))) < 0 || (r = dsc.ensure(units * 512 + 512)) < 0) {
+        release_all();
+        return r;
+    }
+    hipError_t e = hipMemcpy(db.p, blk.data(), (size_t)nblocks * sizeof(J2kBlock), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dby.p, pool.data(), pool.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dc.p, coef, nsamples * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(ds.p, 0, (size_t)nblocks * 4);
+    if (e == hipSuccess) e = hipMemcpy(dw.p, waves.data(), waves.size() * sizeof(MqWave), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t area = mq_lds_area(planes);
+        auto kern = wide ? k_mq_decode<true> : k_mq_decode<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)waves.size()), dim3(64), area + MQ_LDS_TABLES, 0, (const J2kBlock *)db.p, nblocks,
+                           (const uint8_t *)dby.p, (uint32_t *)dc.p, (int *)ds.p, (const MqWave *)dw.p, (uint64_t *)dsc.p, area);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(coef, dc.p, nsamples * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && status) e = hipMemcpy(status, ds.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost);
+    release_all();
+    if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_mq_blocks\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
+    return 0;
+}
+
 extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks, const uint8_t *bytes_in, size_t nbytes_in,
                                void *coef, size_t nsamples, int *status)
 {

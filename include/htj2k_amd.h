@@ -188,6 +188,13 @@ int  htj2k_mct_planes(htj2k_ctx *ctx, void *p0, void *p1, void *p2, int csize, i
  * status[i] != 0: block i was rejected and left zero. */
 int  htj2k_ht_blocks(htj2k_ctx *ctx, const void *blocks, int nblocks, const uint8_t *bytes, size_t nbytes,
                      void *coef, size_t nsamples, int *status);
+/* decode_cblk() + dequantisation (jpeg2000dec.c:1993-2089, 2098-2181) on a table of Part-1 (MQ-coded) blocks:
+ * descriptors with J2K_BLK_PART1 set, bytes laid out as in j2k_plan.h (segments back to back, 0xFF 0xFF behind
+ * terminated ones and behind the last byte, J2kPart1Trailer behind that).  status[i] != 0: decode_cblk() failed
+ * part-way ("bpno became invalid", "Missing needed termination"); `coef` then holds the passes decoded up to there,
+ * which is what the reference dequantises (jpeg2000dec.c:2275-2290). */
+int  htj2k_mq_blocks(htj2k_ctx *ctx, const void *blocks, int nblocks, const uint8_t *bytes, size_t nbytes,
+                     void *coef, size_t nsamples, int *status);
 /* codeblocks the HT decoder rejected in the job's last run (they are left zero) */
 int  htj2k_job_block_errors(htj2k_ctx *ctx, htj2k_job *job);
 int  htj2k_job_num_blocks(const htj2k_job *job);

@@ -183,6 +183,54 @@ def ht_decode_block(data, lcup, lref, npasses, zbp, w, h, M_b, roi_shift=0, vsc=
     return r, out
 
 
+def mq_needs_termination(style, passno):
+    """needs_termination(), libavcodec/jpeg2000.h:302-317"""
+    if style & 1:
+        typ, k = passno % 3, passno // 3
+        if typ == 0 and k > 2:
+            return 2
+        if typ == 2 and k > 2:
+            return 1
+        if style & 4:
+            return 2 if k > 2 else 1
+    return 1 if style & 4 else 0
+
+
+def mq_block_layout(segbytes, seglens, segpasses, style):
+    """Lay the codeword segments of one Part-1 block out as the reference's Tier-2 does (jpeg2000dec.c:1236-1253,
+    1508-1516): 0xFF 0xFF and a data_start entry behind every segment whose last pass needs a termination.
+    -> (data bytes, length, [data_start[1..]])"""
+    data, starts, pos, passno = b"", [], 0, 0
+    for ln, npz in zip(seglens, segpasses):
+        data += segbytes[pos:pos + ln]
+        pos += ln
+        passno += npz
+        if mq_needs_termination(style, passno - 1):
+            data += b"\xff\xff"
+            starts.append(len(data))
+    return data, len(data), starts
+
+
+def mq_decode_block(data, length, npasses, nonzerobits, w, h, M_b, style=0, bandpos=0, starts=(), roi_shift=0):
+    """decode_cblk on the laid-out bytes -> (ret, int32[h, w] sign-magnitude samples)"""
+    buf = ctypes.create_string_buffer(bytes(data) + b"\0" * 16, len(data) + 16)
+    out = np.zeros((h, w), dtype=np.int32)
+    st = (ctypes.c_uint16 * (len(starts) + 2))(0, *starts)          # data_start[0] is never read
+    r = lib().orc_mq_decode_block(buf, length, npasses, nonzerobits, w, h, M_b, roi_shift, style, bandpos, len(starts), st,
+                                  out.ctypes.data_as(ctypes.c_void_p), w)
+    return r, out
+
+
+def mq_block_region(data, length, style, bandpos, starts):
+    """the block's region of the byte pool as ffmpeg-ht_amd/csrc/j2k_plan.h describes it: bytes, 0xFF 0xFF, trailer"""
+    import struct
+    body = bytes(data[:length]) + b"\xff\xff"
+    body += b"\0" * ((-len(body)) % 4)
+    assert len(body) == (length + 2 + 3) & ~3
+    body += struct.pack("<BBH", style, bandpos, len(starts)) + b"".join(struct.pack("<H", v) for v in starts)
+    return body + b"\0" * ((-len(body)) % 16)
+
+
 def _border(b):
     arr = (ctypes.c_int * 4)(b[0][0], b[0][1], b[1][0], b[1][1])
     return arr

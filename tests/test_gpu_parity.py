@@ -373,6 +373,64 @@ def test_openjpeg_encoded_part1_streams(dec, orc, name):
     assert np.abs(planes[0].reshape(pix.shape).astype(np.int64) - pix.astype(np.int64)).max() <= tol
 
 
+def test_part1_block_decoder_unit(dec):
+    """htj2k_mq_blocks = decode_cblk + dequantization_int on single blocks: shapes incl. 1-wide, 1024 x 4, 4 x 1024 and
+    odd sizes, every mode switch, ROI up-shift, and the two ways decode_cblk() fails part-way (the passes decoded up to
+    there stay and are dequantised, jpeg2000dec.c:2275-2290)"""
+    import ffmpeg_ht_amd as m
+    rng = np.random.default_rng(78)
+    descs, pool, expect, soff = [], b"", [], 0
+
+    def add(vals, seg, lens, passes, K, npasses, style, band, M_b, roi=0, npasses_sig=None, drop_starts=0):
+        nonlocal pool, soff
+        h, w = vals.shape
+        data, length, starts = oracle.mq_block_layout(seg, lens, passes, style)
+        npz = npasses if npasses_sig is None else npasses_sig
+        if npz > npasses:
+            starts = starts + [length] * (npz - npasses)
+        if drop_starts:
+            starts = starts[:-drop_starts]
+        ret, t1 = oracle.mq_decode_block(data, length, npz, K, w, h, M_b, style, band, starts, roi_shift=roi)
+        want = np.zeros((h, w), dtype=np.int32)
+        oracle.lib().orc_dequant_int(t1.ctypes.data_as(ctypes.c_void_p), w, want.ctypes.data_as(ctypes.c_void_p), w, w, h, M_b, 32768)
+        d = m.BlockDesc()
+        d.data_off, d.plane_off, d.lcup, d.lref, d.w, d.h, d.stride = len(pool), soff, length, len(starts), w, h, w
+        d.npasses, d.zbp, d.M_b, d.flags, d.roi_shift, d.f_step, d.i_step = npz, K, M_b, 4 | 1, roi, 1.0, 32768
+        descs.append(d)
+        pool += oracle.mq_block_region(data, length, style, band, starts)
+        expect.append((soff, want, ret))
+        soff += w * h
+
+    import vecgen
+    for style in (0, 0x01, 0x04, 0x08, 0x2F):
+        for (w, h) in [(64, 64), (32, 32), (63, 61), (1, 1), (3, 5), (1, 40), (40, 1), (1024, 4), (4, 1024), (128, 32), (17, 200)]:
+            for amp, density in ((1, 0.05), (200, 1.0), (30000, 1.0)):
+                band = int(rng.integers(0, 4))
+                vals = rng.integers(-amp, amp + 1, (h, w)) * (rng.random((h, w)) < density)
+                vals[0, 0] = amp
+                seg, lens, passes, K, npasses = vecgen.encode_block_p1(vals, band=band, style=style)
+                add(vals, seg, lens, passes, K, npasses, style, band, K + 2)
+    # ROI up-shift of the samples below the threshold (jpeg2000dec.c:2071-2086)
+    vals = rng.integers(-9, 10, (32, 32))
+    vals[0, 0] = 9
+    seg, lens, passes, K, npasses = vecgen.encode_block_p1(vals, band=2, style=0)
+    add(vals, seg, lens, passes, K + 3, npasses, 0, 2, K + 6, roi=3)
+    # "bpno became invalid" part-way, "Missing needed termination" part-way, "bpno invalid" before the first pass
+    vals = rng.integers(-50, 51, (32, 32))
+    vals[0, 0] = 50
+    seg, lens, passes, K, npasses = vecgen.encode_block_p1(vals, band=1, style=0x04)
+    add(vals, seg, lens, passes, K, npasses, 0x04, 1, 28, npasses_sig=npasses + 9)
+    add(vals, seg, lens, passes, K, npasses, 0x04, 1, K + 2, drop_starts=3)
+    add(vals, seg, lens, passes, 31, npasses, 0x04, 1, 9)
+    got, status = dec.mq_blocks(descs, pool, soff)
+    nerr = 0
+    for i, (o, want, ret) in enumerate(expect):
+        assert (status[i] != 0) == (ret < 0), i
+        nerr += ret < 0
+        assert np.array_equal(got[o:o + want.size].reshape(want.shape), want), i
+    assert nerr == 3
+
+
 def test_part1_and_ht_frames_in_one_batch(dec, orc):
     """HT and Part-1 blocks share a job: the HT kernels take the front of the block table, k_mq_decode the rest"""
     names = ["p1_rgb_mct", "rgb_mct", "p1_bypass_termall", "gray_3passes", "p1_gray_cb4x1024", "p1_97", "yuv422p12_97",

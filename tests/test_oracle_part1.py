@@ -92,3 +92,43 @@ def test_mq_state_table_checksum(orc):
     assert list(nm[:12]) == [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 76, 77]
     assert list(nl[:12]) == [3, 2, 12, 13, 18, 19, 24, 25, 58, 59, 66, 67]
     assert (nm[92], nm[93], nl[92], nl[93]) == (92, 93, 92, 93)
+
+
+def _p1_block_case(rng, w, h, amp, density, style, band):
+    import vecgen
+    vals = rng.integers(-amp, amp + 1, (h, w)) * (rng.random((h, w)) < density)
+    vals[0, 0] = amp                                   # never all zero
+    seg, lens, passes, K, npasses = vecgen.encode_block_p1(vals, band=band, style=style)
+    return vals, seg, lens, passes, K, npasses
+
+
+@pytest.mark.parametrize("style", [0, 0x01, 0x02, 0x04, 0x08, 0x20, 0x05, 0x2F])
+def test_block_level_round_trip(style):
+    """decode_cblk() on single blocks from the factory's EBCOT encoder: shapes incl. 1-wide, 1024 x 4, odd sizes"""
+    rng = np.random.default_rng(100 + style)
+    for (w, h) in [(64, 64), (32, 32), (63, 61), (1, 1), (3, 5), (1, 40), (40, 1), (1024, 4), (4, 1024), (128, 32), (17, 200)]:
+        for amp, density in ((1, 0.05), (3, 0.5), (200, 1.0), (30000, 1.0)):
+            for band in (0, 1, 3):
+                vals, seg, lens, passes, K, npasses = _p1_block_case(rng, w, h, amp, density, style, band)
+                M_b = K + 2
+                data, length, starts = oracle.mq_block_layout(seg, lens, passes, style)
+                ret, t1 = oracle.mq_decode_block(data, length, npasses, K, w, h, M_b, style, band, starts)
+                assert ret == 1
+                mag = (t1 & 0x7FFFFFFF) >> (31 - M_b)
+                assert np.array_equal(np.where(t1 < 0, -mag, mag), vals), (w, h, amp, style, band)
+
+
+def test_block_level_errors_keep_the_decoded_passes():
+    """"bpno became invalid" and "Missing needed termination": decode_cblk() fails part-way and the reference goes
+    on to dequantise what is there (jpeg2000dec.c:2019-2022, 2040-2043, 2275-2290)"""
+    rng = np.random.default_rng(5)
+    vals, seg, lens, passes, K, npasses = _p1_block_case(rng, 32, 32, 50, 1.0, 0x04, 1)
+    data, length, starts = oracle.mq_block_layout(seg, lens, passes, 0x04)
+    ret_ok, good = oracle.mq_decode_block(data, length, npasses, K, 32, 32, K + 2, 0x04, 1, starts)
+    assert ret_ok == 1
+    # more passes signalled than bit-planes exist: the bit-plane counter runs below zero
+    ret, part = oracle.mq_decode_block(data, length, npasses + 9, K, 32, 32, 28, 0x04, 1, starts + [length] * 9)
+    assert ret < 0 and part.any()
+    # a TERMALL block that lost its last three segment starts
+    ret, part = oracle.mq_decode_block(data, length, npasses, K, 32, 32, K + 2, 0x04, 1, starts[:-3])
+    assert ret < 0 and part.any() and not np.array_equal(part, good)

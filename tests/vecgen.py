@@ -118,6 +118,25 @@ def encode_block(vals, passes=1, causal=False):
     return data, lcup.value, lref.value, mu.value
 
 
+def encode_block_p1(vals, band=0, style=0, drop_passes=0):
+    """vals: 2-D int array of quantisation indices -> (segment bytes back to back, [segment lengths], [passes per
+    segment], bit-planes K, coding passes)"""
+    a = np.ascontiguousarray(vals, dtype=np.int32)
+    h, w = a.shape
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    kb, npz, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    seglen, segpasses = (ctypes.c_int * 128)(), (ctypes.c_int * 128)()
+    r = lib().htj2k_encode_block_p1(a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), w, h, band, style, drop_passes,
+                                    ctypes.byref(out), ctypes.byref(kb), ctypes.byref(npz), ctypes.byref(ns), seglen, segpasses)
+    if r != 0:
+        raise RuntimeError("htj2k_encode_block_p1 failed: %d" % r)
+    lens = [seglen[i] for i in range(ns.value)]
+    data = ctypes.string_at(out, sum(lens)) if kb.value else b""
+    if kb.value:
+        lib().htj2k_enc_free(out)
+    return data, lens, [segpasses[i] for i in range(ns.value)], kb.value, npz.value
+
+
 def jp2_wrap(codestream, width, height, ncomp, depth, colourspace=None, cdef=None, res=None, palette=None):
     """Minimal JP2 file around a codestream (jP signature, ftyp, jp2h{ihdr,colr[,cdef][,res ]}, jp2c)."""
     import struct

@@ -1518,3 +1518,26 @@ int htj2k_encode_block(const int32_t *vals, int w, int h, int passes, int causal
     *out = b.p;
     return 0;
 }
+
+/* One Part-1 block for block-level unit tests: vals = w*h signed quantisation indices, band 0 LL / 1 HL / 2 LH / 3 HH,
+ * style = mode switches.  Returns the codeword segments back to back, their lengths and pass counts, the number of
+ * magnitude bit-planes (= cblk->nonzerobits) and of coding passes. */
+int htj2k_encode_block_p1(const int32_t *vals, int w, int h, int band, int style, int drop_passes,
+                          uint8_t **out, int *kbits, int *npasses, int *nseg, int *seglen, int *segpasses)
+{
+    Buf b = { 0 };
+    int i, ret;
+    uint32_t *mag = (uint32_t *)malloc(sizeof(uint32_t) * w * h);
+    uint8_t  *sgn = (uint8_t *)malloc((size_t)w * h);
+    if (!mag || !sgn) { free(mag); free(sgn); return -1; }
+    for (i = 0; i < w * h; i++) {
+        mag[i] = (uint32_t)(vals[i] < 0 ? -(int64_t)vals[i] : vals[i]);
+        sgn[i] = vals[i] < 0;
+    }
+    ret = p1_encode_block(mag, sgn, w, h, band, style, drop_passes, &b, kbits, npasses, nseg, seglen, segpasses);
+    free(mag); free(sgn);
+    if (ret || b.oom) { free(b.p); return ret ? ret : -1; }
+    for (i = 0; i < 8; i++) buf_u8(&b, 0);
+    *out = b.p;
+    return 0;
+}

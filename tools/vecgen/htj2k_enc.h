@@ -48,6 +48,8 @@ int  htj2k_encode(const htj2k_enc_params *P, const int32_t *const comps[4], uint
 void htj2k_enc_free(uint8_t *p);
 int  htj2k_encode_block(const int32_t *vals, int w, int h, int passes, int causal,
                         uint8_t **out, int *lcup, int *lref, int *max_U);
+int  htj2k_encode_block_p1(const int32_t *vals, int w, int h, int band, int style, int drop_passes,
+                           uint8_t **out, int *kbits, int *npasses, int *nseg, int *seglen, int *segpasses);
 #ifdef __cplusplus
 }
 #endif
