@@ -5,6 +5,8 @@
  *   htj2k_decode in.j2c [out.raw]            one codestream / JP2 file -> raw planes (plane after plane, tight rows)
  *   htj2k_decode -p N in.j2c [out.raw]       the same packet N times through the asynchronous pipeline
  *                                            (htj2k_pipe_*), frames written are those of the last round
+ *   htj2k_decode -s in.j2k [out.raw]         a sequence of back-to-back codestreams / JP2 files: cut into packets by
+ *                                            htj2k_splitter_* (64 KB reads), every frame decoded and written
  *
  * build: make examples   (cc examples/htj2k_decode.c -Iinclude -Lffmpeg-ht_amd -lhtj2k_amd)
  */
@@ -40,11 +42,58 @@ static int alloc_planes(const htj2k_info *info, htj2k_frame *fr)
     return 0;
 }
 
+/* -s: the file is a sequence of frames; what av_parser_parse2() + avcodec_send_packet() do in the reference */
+static int decode_sequence(const char *in, const char *outname)
+{
+    FILE *f = fopen(in, "rb"), *o = outname ? fopen(outname, "wb") : NULL;
+    if (!f || (outname && !o)) { perror(f ? outname : in); return 2; }
+    htj2k_opts opts;
+    memset(&opts, 0, sizeof(opts));
+    opts.req_pix_fmt = HTJ2K_PIX_NONE;
+    htj2k_ctx *ctx = NULL;
+    htj2k_splitter *sp = NULL;
+    int r = htj2k_open(&opts, &ctx);
+    if (r < 0 || (r = htj2k_splitter_open(&sp)) < 0) { fprintf(stderr, "open: %d\n", r); return 1; }
+    htj2k_set_log(ctx, log_cb, NULL);
+    static uint8_t chunk[65536 + 64];
+    int nframes = 0, eof = 0;
+    while (!eof) {
+        int n = (int)fread(chunk, 1, 65536, f), pos = 0;
+        eof = n == 0;                                        /* a final call with size 0 flushes the last frame */
+        memset(chunk + n, 0, 64);
+        do {
+            const uint8_t *frame = NULL;
+            int fsize = 0;
+            int used = htj2k_splitter_parse(sp, chunk + pos, n - pos, &frame, &fsize);
+            if (used < 0) { fprintf(stderr, "htj2k_splitter_parse: %d\n", used); return 1; }
+            pos += used;
+            if (frame && fsize > 0) {
+                htj2k_info info;
+                htj2k_frame fr;
+                if ((r = htj2k_probe(ctx, frame, fsize, &info)) < 0 || alloc_planes(&info, &fr) < 0 ||
+                    (r = htj2k_decode(ctx, frame, fsize, &fr, NULL)) < 0) { fprintf(stderr, "frame %d: %d\n", nframes, r); return 1; }
+                for (int p = 0; o && p < info.nplanes; p++)
+                    fwrite(fr.data[p], 1, (size_t)fr.linesize[p] * info.plane_height[p], o);
+                for (int p = 0; p < 4; p++) free(fr.data[p]);
+                printf("frame %d: %d bytes, %dx%d pix_fmt %d\n", nframes++, fsize, info.width, info.height, info.pix_fmt);
+            } else if (used == 0) {
+                break;
+            }
+        } while (pos < n);
+    }
+    if (o) fclose(o);
+    fclose(f);
+    htj2k_splitter_close(sp);
+    htj2k_close(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int npipe = 0, a = 1;
+    if (argc > 2 && !strcmp(argv[1], "-s")) return decode_sequence(argv[2], argc > 3 ? argv[3] : NULL);
     if (argc > 2 && !strcmp(argv[1], "-p")) { npipe = atoi(argv[2]); a = 3; }
-    if (argc <= a) { fprintf(stderr, "usage: %s [-p N] in.j2c [out.raw]\n", argv[0]); return 2; }
+    if (argc <= a) { fprintf(stderr, "usage: %s [-p N | -s] in.j2c [out.raw]\n", argv[0]); return 2; }
     FILE *f = fopen(argv[a], "rb");
     if (!f) { perror(argv[a]); return 2; }
     fseek(f, 0, SEEK_END);

@@ -564,3 +564,16 @@ def test_c_example_program(orc, tmp_path):
             r = subprocess.run([exe] + extra + [str(src), str(out)], capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, (r.stdout, r.stderr)
             assert out.read_bytes() == want, (name, extra)
+    # -s: a sequence of different frames in one file, cut apart by htj2k_splitter_* in 64 KB reads
+    names = ["rgb_mct", "p1_bypass_termall", "gray16", "mixed_rgb_cb32", "rgb_mct"]
+    seq = tmp_path / "sequence.j2k"
+    seq.write_bytes(b"".join(streams.get(n)[0] for n in names))
+    want = b""
+    for n in names:
+        _, planes_o, _ = orc.decode(streams.get(n)[0])
+        want += b"".join(np.ascontiguousarray(p).tobytes() for p in planes_o)
+    out = tmp_path / "sequence.raw"
+    r = subprocess.run([exe, "-s", str(seq), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.count("frame ") == len(names), r.stdout
+    assert out.read_bytes() == want
