@@ -1,5 +1,5 @@
 /* fuzz_parse.c -- test harness (built with -fsanitize=address,undefined by tests/test_parser_fuzz.py): mutated
- * codestreams through the host parser j2k_parse().  Every packet is copied into an exact-size heap buffer, so an
+ * codestreams through the host parser j2k_parse() and the frame splitter htj2k_splitter_*.  Every packet is copied into an exact-size heap buffer, so an
  * over-read of the packet is an ASan report; every accepted plan is checked the way the device layer would walk it
  * (block bytes inside the byte pool, block windows inside the coefficient planes).
  * usage: fuzz_parse ITERATIONS file... */
@@ -25,8 +25,24 @@ int main(int argc,char**argv){
       const J2kPlan*pl=NULL; o.reduction_factor = (it%7==0)? rnd()%4 : 0;
       int r=j2k_parse(p,c,(int)m,&o,0,&pl); total++; if(r>=0) { ok++;
         /* touch everything the device layer would read */
-        volatile uint64_t acc=0; for(int i=0;i<pl->nblocks;i++){ const J2kBlock*bk=pl->blocks+i; size_t e=(size_t)bk->data_off+bk->lcup+bk->lref; if(e>pl->nbytes){printf("block %d overruns pool\n",i);abort();} if(bk->lcup+bk->lref) acc+=pl->bytes[e-1]; if((size_t)bk->plane_off + (size_t)(bk->h-1)*bk->stride + bk->w > pl->nsamples){printf("block %d outside planes\n",i);abort();} }
+        volatile uint64_t acc=0; for(int i=0;i<pl->nblocks;i++){ const J2kBlock*bk=pl->blocks+i; size_t e=(size_t)bk->data_off+bk->lcup+bk->lref;
+          if(bk->flags & J2K_BLK_PART1){                    /* bytes + 0xFF 0xFF + trailer with the segment starts */
+            const J2kPart1Trailer*tr=(const J2kPart1Trailer*)(pl->bytes+bk->data_off+J2K_P1_TRAILER_OFF(bk->lcup));
+            e=(size_t)bk->data_off+J2K_P1_TRAILER_OFF(bk->lcup)+4+2*(size_t)bk->lref;
+            if(e>pl->nbytes){printf("Part-1 block %d overruns pool\n",i);abort();}
+            if(tr->nterm!=bk->lref||pl->bytes[bk->data_off+bk->lcup]!=0xFF||pl->bytes[bk->data_off+bk->lcup+1]!=0xFF){printf("Part-1 block %d: bad trailer\n",i);abort();}
+            for(int k=0;k<tr->nterm;k++) if(tr->start[k]>bk->lcup){printf("Part-1 block %d: segment start outside\n",i);abort();}
+            e=(size_t)bk->data_off+bk->lcup+2; } if(e>pl->nbytes){printf("block %d overruns pool\n",i);abort();} if(bk->lcup+bk->lref) acc+=pl->bytes[e-1]; if((size_t)bk->plane_off + (size_t)(bk->h-1)*bk->stride + bk->w > pl->nsamples){printf("block %d outside planes\n",i);abort();} }
       }
+      /* the same bytes, twice over, through the frame splitter in random pieces (exact-size buffers again) */
+      { htj2k_splitter*sp=NULL; if(htj2k_splitter_open(&sp)<0) abort();
+        long pos=0, tot=2*m; int frames=0;
+        while(pos<tot){ long k=1+rnd()%(tot-pos<4096?tot-pos:4096); uint8_t*q=malloc(k); for(long t=0;t<k;t++) q[t]=c[(pos+t)%(m?m:1)];
+          long off=0; while(off<k){ const uint8_t*fr=NULL; int fs=0; int used=htj2k_splitter_parse(sp,q+off,(int)(k-off),&fr,&fs); if(used<0) break;
+            if(fr&&fs>0){ volatile uint8_t t0=fr[0], t1=fr[fs-1]; (void)t0;(void)t1; frames++; } off+=used; if(!used&&!fr) break; }
+          free(q); pos+=k; }
+        { const uint8_t*fr=NULL; int fs=0; htj2k_splitter_parse(sp,NULL,0,&fr,&fs); if(fr&&fs>0){ volatile uint8_t t1=fr[fs-1]; (void)t1; } }
+        htj2k_splitter_close(sp); (void)frames; }
       free(c);
     }
     free(b);
