@@ -328,7 +328,12 @@ def main():
                          "achieved_min_hbm_traffic": round(achieved_hbm, 1),
                          "frac_min_hbm_traffic": round(achieved_hbm / HBM_PEAK_GBS, 4),
                          "min_hbm_MB_per_launch": round(idwt_launch_hbm / max(nlaunch, 1) / 1e6, 3),
-                         "copy_ceiling": COPY_CEILING_GBS},
+                         "copy_ceiling": COPY_CEILING_GBS,
+                         "sub_bands_16bit": bool(jobs[0].coef16()),
+                         "note": "achieved/frac count SURVEY 8(d)'s algorithmic bytes (4 B per sample read and written "
+                                 "per level); when sub_bands_16bit is true the sub-bands really move as 2 B samples (exact "
+                                 "for this workload: every band has M_b <= 15), so frac can exceed the share of the bus "
+                                 "that is busy -- *_min_hbm_traffic and `traffic` count the bytes that really move"},
             "stage_ms_per_step_sum_over_jobs": {"ht_decode_dequant": round(ht_ms / args.steps, 4),
                                                 "idwt": round(idwt_ms / args.steps, 4),
                                                 "mct_pack": round(pack_ms / args.steps, 4)},

@@ -119,7 +119,10 @@ struct DwtFusedArgs {
  * has a data-dependent trip count: the compiler can then keep the next step's loads in
  * flight across the current step (s_waitcnt vmcnt(N > 0)).  FAST && FUSED is the rgb24 case:
  * three 8-bit components on one packed plane. */
-template <int TYPE, int NC, bool FUSED, bool FAST>
+/* C16: the sub-bands the block decoder wrote are 16-bit samples (the coefficient buffer read as int16_t with the same
+ * element offsets; reversible 5/3 planes whose bands all have M_b <= 15, see htj2k_device.hip); LL16: so is the LL band,
+ * i.e. this is the first level.  Both only on the FAST path (aligned sample pairs). */
+template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
@@ -181,7 +184,28 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         }
         /* even absolute rows are vertical-low rows (the reflection keeps the parity): their
          * low-horizontal half is the previous level's output */
-        if (FAST || interior) {
+        if (C16) {
+            static_assert(!C16 || FAST, "16-bit sub-bands: fast path only");
+            auto lo16 = [](uint32_t v) { return (uint32_t)(int32_t)(int16_t)(v & 0xFFFFu); };
+            auto hi16 = [](uint32_t v) { return (uint32_t)((int32_t)v >> 16); };
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const uint16_t *b16 = (const uint16_t *)band_base + A[c].g.plane_off;
+                const uint16_t *brow0 = b16 + (size_t)iy[0] * A[c].g.stride, *brow1 = b16 + (size_t)iy[1] * A[c].g.stride;
+                const uint32_t lo = *(const uint32_t *)(brow0 + col[1]);        /* col[] are even here: aligned pairs */
+                const uint32_t he = *(const uint32_t *)(brow1 + col[0]), ho = *(const uint32_t *)(brow1 + col[1]);
+                if (LL16) {
+                    const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)iy[0] * A[c].ll_stride;
+                    const uint32_t le = *(const uint32_t *)(lrow + col[0]);
+                    Lr[c][0] = lo16(le); Lr[c][2] = hi16(le);
+                } else {
+                    const uint2 le = *(const uint2 *)(llp[c] + (size_t)iy[0] * A[c].ll_stride + col[0]);
+                    Lr[c][0] = le.x; Lr[c][2] = le.y;
+                }
+                Lr[c][1] = lo16(lo); Lr[c][3] = hi16(lo);
+                Hr[c][0] = lo16(he); Hr[c][1] = lo16(ho); Hr[c][2] = hi16(he); Hr[c][3] = hi16(ho);
+            }
+        } else if (FAST || interior) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const uint32_t *lrow = llp[c] + (size_t)iy[0] * A[c].ll_stride;
@@ -429,13 +453,14 @@ __host__ __device__ inline bool stream_fast_rgb24(const PackTile &T, const DwtLe
            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
 }
 
-template <int TYPE, int NC, bool FUSED, bool FASTONLY>
+template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false>
 __device__ __forceinline__ void
 idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
 {
+    static_assert(!C16 || FASTONLY, "16-bit sub-bands: FASTONLY launches only");
     if (FASTONLY) {
-        idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
     } else {                                               /* per-wave choice; all conditions are wave-uniform */
         bool fast = stream_fast_geom(A[0].g);
         if (FUSED) fast = fast && stream_fast_rgb24(*T, A[0].g, NC, comp0);
@@ -464,7 +489,7 @@ __device__ __forceinline__ bool stream_strip(const StreamGrid &G, int &bx, int &
 }
 
 /* plain level: one DwtTileArgs table entry per plane, blockDim = one wave */
-template <int TYPE, bool FASTONLY>
+template <int TYPE, bool FASTONLY, bool C16 = false, bool LL16 = false>
 __global__ void __launch_bounds__(64)
 k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
               const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G)
@@ -472,11 +497,11 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
     int bx, by, bz;
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
-    idwt_stream_body<TYPE, 1, false, FASTONLY>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by);
+    idwt_stream_body<TYPE, 1, false, FASTONLY, C16, LL16>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by);
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
-template <int TYPE, int NC, bool FASTONLY>
+template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false>
 __global__ void __launch_bounds__(64)
 k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th, StreamGrid G)
@@ -487,7 +512,7 @@ k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__rest
     DwtTileArgs A[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) A[c] = F.a[c];
-    idwt_stream_body<TYPE, NC, true, FASTONLY>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
+    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
 }
 
 }  // namespace htj2k

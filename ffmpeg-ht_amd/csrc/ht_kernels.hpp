@@ -190,6 +190,13 @@ __device__ __forceinline__ void ht_zero_window(uint32_t *dst, int w, int h, int 
             dst[(size_t)y * stride + x] = 0u;
 }
 
+__device__ __forceinline__ void ht_zero_window16(uint16_t *dst, int w, int h, int stride, int lane)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = lane; x < w; x += 64)
+            dst[(size_t)y * stride + x] = 0;
+}
+
 __device__ __forceinline__ int bm_get(const uint32_t *bm, int idx) { return (bm[idx >> 5] >> (idx & 31)) & 1; }
 
 /* ---- MagSgn fast path: blocks of at most 64 sample columns, no ROI shift ----
@@ -247,7 +254,9 @@ __device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict_
     return base;
 }
 
-template <int TRANSFORM, bool REFINE>
+/* C16: the plane is written as 16-bit samples (`dst` then points at int16_t elements; 5/3 blocks with M_b <= 15
+ * only: every dequantised value fits, see htj2k_device.hip) */
+template <int TRANSFORM, bool REFINE, bool C16 = false>
 __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
                                                      uint32_t *__restrict__ dst, int lane, int w, int h,
                                                      int stride, int pLSB, int maxbp, int M_b, float fscale, int i_step,
@@ -271,6 +280,7 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
     const uint32_t *qp = qglob + q;
     uint32_t qi_next = act ? *qp : 0u;
     uint32_t *prow = dst + col;                            /* this lane's column, row 2 * row */
+    uint16_t *prow16 = (uint16_t *)dst + col;              /* the same under C16 */
     for (int row = 0; row < qh; row++) {
         const uint32_t qi = qi_next;
         qp += qwp;
@@ -376,10 +386,16 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
              * have nothing to write aim at a scratch dword.  With a fixed number of stores behind
              * the prefetch of the next row's symbols the wait at the loop top is vmcnt(2), not
              * vmcnt(0) -- the rows of a block no longer wait for each other's stores to land. */
-            *(st_ok ? prow : sink) = o_t;
-            *((st_ok && two) ? prow + stride : sink) = o_b;
+            if (C16) {
+                *(st_ok ? prow16 : (uint16_t *)sink) = (uint16_t)o_t;
+                *((st_ok && two) ? prow16 + stride : (uint16_t *)sink) = (uint16_t)o_b;
+            } else {
+                *(st_ok ? prow : sink) = o_t;
+                *((st_ok && two) ? prow + stride : sink) = o_b;
+            }
         }
         prow += 2 * stride;
+        prow16 += 2 * stride;
     }
     return __any(err) ? HT_ERR_INVALID : 0;
 }
@@ -393,7 +409,8 @@ __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
             int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
-            uint32_t *__restrict__ sink, const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
+            uint32_t *__restrict__ sink, const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff,
+            int coef16 = 0)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -402,10 +419,13 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     const int w = b.w, h = b.h, stride = b.stride;
     const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
     const int transform = b.flags & 3;
-    uint32_t *dst = coef + b.plane_off;
+    /* coef16 (host-checked: every block of the job is a reversible 5/3 cleanup-only block of at most 64 columns
+     * with M_b <= 15 and no ROI shift): the planes are written as int16_t, same element offsets */
+    uint16_t *dst16 = (uint16_t *)coef + b.plane_off;
+    uint32_t *dst = coef16 ? (uint32_t *)dst16 : coef + b.plane_off;
 
     if (b.npasses == 0) {                              /* not coded: the reference plane is calloc'ed */
-        ht_zero_window(dst, w, h, stride, lane);
+        if (coef16) ht_zero_window16(dst16, w, h, stride, lane); else ht_zero_window(dst, w, h, stride, lane);
         return;
     }
     /* pass bookkeeping, jpeg2000htdec.c:1240-1264 */
@@ -432,7 +452,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
                  (!EXTERNAL_VLC && ((Scup * 8 + 31) / 32 + 2 > L.vlc_words || Scup > L.suf_bytes))))
         err = HT_ERR_INVALID;
     if (err) {
-        ht_zero_window(dst, w, h, stride, lane);
+        if (coef16) ht_zero_window16(dst16, w, h, stride, lane); else ht_zero_window(dst, w, h, stride, lane);
         if (lane == 0) status[blockIdx.x] = err;
         return;
     }
@@ -524,6 +544,8 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
             else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
             else err = ht_magsgn_rows_narrow<J2K_DWT97_INT, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
+        } else if (EXTERNAL_VLC && coef16) {
+            err = ht_magsgn_rows_narrow<J2K_DWT53, false, true>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
         } else {
             if (transform == J2K_DWT53) err = ht_magsgn_rows_narrow<J2K_DWT53, false>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
             else if (transform == J2K_DWT97) err = ht_magsgn_rows_narrow<J2K_DWT97, false>(qglob, ms, dst, lane, w, h, stride, pLSB, maxbp, M_b, fscale, i_step, nms - 2, sink, rbits, z_blk);
@@ -684,7 +706,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
 
     if (err) {
         __syncthreads();
-        ht_zero_window(dst, w, h, stride, lane);
+        if (coef16) ht_zero_window16(dst16, w, h, stride, lane); else ht_zero_window(dst, w, h, stride, lane);
         if (lane == 0) status[blockIdx.x] = err;
         return;
     }

@@ -82,6 +82,8 @@ struct htj2k_ctx {
     int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = LDS + register/DPP tile kernel,
                                         * 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
+    int coef16 = 1;                    /* 1: reversible jobs whose coefficients fit 16 bits keep them as int16_t between the
+                                        * block decoder and the IDWT (see coef16_ok) */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
     int parse_threads = 0;             /* host threads that parse the frames of a batch; 0 = min(cores, 16) */
@@ -126,6 +128,11 @@ struct htj2k_job {
     std::vector<double> lev_bytes, lev_hbm;   /* algorithmic / least-HBM bytes of each recorded launch */
     DevBuf d_bytes, d_blocks, d_status, d_coef, d_t0, d_t1, d_desc, d_qsym, d_qoff, d_vlcu, d_melu, d_reflist, d_roff, d_refbits;
     /* Part-1 (MQ-coded) blocks sit behind the HT blocks in `blocks`: [nht, blocks.size()) */
+    /* every sample the block decoder writes fits int16_t and only the FASTONLY streaming IDWT kernels read them: all
+     * planes coded, reversible 5/3 with at least one level, all blocks HT cleanup-only, <= 64 columns, M_b <= 15,
+     * step size 1, no ROI shift, all levels of fast geometry.  The sub-bands then travel as 2 bytes per sample. */
+    bool coef16_ok = false;
+    bool coef_is16 = false;            /* what the last HT stage run actually wrote */
     int nht = 0;
     std::vector<MqWave> mqwaves;       /* one per 64 Part-1 blocks */
     size_t mq_scratch_units = 0;       /* 512-byte row slots of k_mq_decode's scratch */
@@ -260,6 +267,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "fuse_pack")) { c->fuse_pack = value ? 1 : 0; return 0; }
     if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
     return HTJ2K_ERR_EINVAL;
@@ -889,6 +897,24 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
     }
     if ((r = build_descriptors(c, j)) < 0) return r;
+    {
+        bool ok = j->nht == (int)j->blocks.size() && j->reflist.empty() && j->tile_ok && j->any_fusable && !j->blocks.empty();
+        for (size_t t = 0; ok && t < j->tilecomps.size(); t++) {
+            const J2kTileComp &tc = j->tilecomps[t];
+            ok = tc.coded && tc.transform == J2K_DWT53 && tc.ndeclevels >= 1;
+        }
+        for (size_t i = 0; ok && i < j->blocks.size(); i++) {
+            const J2kBlock &b = j->blocks[i];
+            ok = b.w <= 64 && b.M_b <= 15 && b.roi_shift == 0 && b.i_step == 32768 && (b.flags & 3) == J2K_DWT53;
+            if (ok && b.npasses) { const int rem = b.npasses % 3; ok = b.npasses - (rem ? b.npasses - rem : b.npasses - 3) == 1; }
+        }
+        for (size_t i = 0; ok && i < j->launches_fused.size(); i++) {
+            const LevelLaunch &L = j->launches_fused[i];
+            ok = L.all_fast && L.type == J2K_DWT53 && L.min_l >= 2 && (L.nc == 0 || L.nc == 3);
+        }
+        for (size_t i = 0; ok && i < j->tile_fusable.size(); i++) ok = j->tile_fusable[i] != 0;
+        j->coef16_ok = ok;
+    }
     if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
     for (int f = 0; f < j->nframes; f++) {
@@ -958,13 +984,15 @@ static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count)
 
 template <int TYPE>
 static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min_l, int count, int mode, hipStream_t s,
-                                const uint32_t *ll, const uint32_t *band, uint32_t *out, bool all_fast)
+                                const uint32_t *ll, const uint32_t *band, uint32_t *out, bool all_fast, int coef16 = 0)
 {
     if (mode >= 3 && min_l >= 2) {
         const int th = stream_strip_rows(max_lh, max_lv, count);
         const StreamGrid G = stream_grid(max_lh, max_lv, th, count);
         dim3 g(8 * G.per_xcd);
-        if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        if (TYPE == J2K_DWT53 && coef16 == 2) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        else if (TYPE == J2K_DWT53 && coef16 == 1) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        else if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
         else hipLaunchKernelGGL((k_idwt_stream<TYPE, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
     } else if (mode >= 2 && min_l >= 2) {
         constexpr int TW2 = 128 - 2 * Lift<TYPE>::HALO - 2, TH2 = 64;
@@ -980,7 +1008,8 @@ template <int TYPE>
 static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
 {
     launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
-                              j->stream, ll, (const uint32_t *)j->d_coef.p, out, L.all_fast);
+                              j->stream, ll, (const uint32_t *)j->d_coef.p, out, L.all_fast,
+                              j->coef_is16 ? (L.level == 0 ? 2 : 1) : 0);   /* 16-bit sub-bands; at level 0 the LL band too */
 }
 
 template <int TYPE>
@@ -992,7 +1021,10 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
-    if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: nc == 3, all_fast */
+        if (L.level == 0) hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 3, true, true, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+        else hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 3, true, true, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    } else if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
@@ -1036,7 +1068,12 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
         hipEvent_t e1 = lev_event(j);
         if (e1) (void)hipEventRecord(e1, j->stream);
         j->lev_bytes.push_back(L.alg_bytes);
-        j->lev_hbm.push_back(L.nc ? L.hbm_bytes : L.alg_bytes);
+        /* bytes that have to move: a level reads its LL quarter and three sub-band quarters and writes every sample
+         * (alg_bytes = 8 per sample); the fused level writes the packed pixels instead (hbm_bytes = 4 + out per
+         * sample).  With 16-bit sub-bands three quarters of the reads are 2 bytes (all of them at level 0). */
+        double hb = L.nc ? L.hbm_bytes : L.alg_bytes;
+        if (j->coef_is16) hb -= L.alg_bytes / 8.0 * (L.level == 0 ? 2.0 : 1.5);
+        j->lev_hbm.push_back(hb);
     }
     return 0;
 }
@@ -1067,8 +1104,12 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const MqWave *)j->d_mqwaves.p + nwide, (uint64_t *)j->d_mqscratch.p, area);
             HIP_TRY(c, hipGetLastError());
         }
+        j->coef_is16 = false;
         if (nblocks) {
             const size_t vlc_lds = ht_vlc_lds_bytes(j->max_qw);
+            /* 16-bit sub-bands only when this very call also runs the (fused, streaming) IDWT that reads them */
+            j->coef_is16 = c->coef16 && j->coef16_ok && c->ht_mode == 1 && vlc_lds <= 160 * 1024 && mask == 7 &&
+                           c->idwt_mode == 3 && c->fuse_pack;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
@@ -1096,7 +1137,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
                                    (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                    (uint32_t *)j->d_coef.p + j->nsamples + 32,
-                                   (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
+                                   (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p, j->coef_is16 ? 1 : 0);
             } else {
                 if ((int)j->lds.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
@@ -1192,6 +1233,9 @@ extern "C" int htj2k_job_idwt_launches(htj2k_ctx *c, htj2k_job *j, float *ms, do
     }
     return n;
 }
+
+/* 1 when the last htj2k_job_run kept the sub-bands as 16-bit samples between the block decoder and the IDWT */
+extern "C" int htj2k_job_coef16(const htj2k_job *j) { return j ? (j->coef_is16 ? 1 : 0) : HTJ2K_ERR_EINVAL; }
 
 extern "C" int htj2k_job_idwt_hbm_bytes(htj2k_ctx *c, htj2k_job *j, double *bytes, int cap)
 {

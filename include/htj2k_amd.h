@@ -148,6 +148,10 @@ int  htj2k_job_download_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_f
  * to move through HBM at least: the same figure for a plain level, 4 * lh * lv + the frame bytes
  * written for a final level that is fused with the MCT / pack stage. */
 int  htj2k_job_idwt_launches(htj2k_ctx *ctx, htj2k_job *job, float *ms, double *bytes, int cap);
+/* 1 when the last htj2k_job_run kept the sub-bands as 16-bit samples between the block decoder and the inverse DWT
+ * (exact: reversible 5/3 jobs whose every band has M_b <= 15, rgb24 output, all levels of even geometry; knob
+ * "coef16", default on).  The reference holds them as int32 (comp->i_data, jpeg2000.c:499-511). */
+int  htj2k_job_coef16(const htj2k_job *job);
 int  htj2k_job_idwt_hbm_bytes(htj2k_ctx *ctx, htj2k_job *job, double *bytes, int cap);
 /* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
 int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
@@ -209,6 +213,7 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
+ *   "coef16"      1 (default): jobs that qualify keep the sub-bands as 16-bit samples (htj2k_job_coef16)
  *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
  *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);

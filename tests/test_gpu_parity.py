@@ -354,6 +354,72 @@ def test_truncated_and_garbage_streams_do_not_fault(dec, orc):
         assert planes[0].shape == planes_o[0].shape
 
 
+# ---------------------------------------------------------------- 16-bit sub-bands between block decoder and IDWT
+def _coef16_streams():
+    """8-bit RGB + RCT frames whose every IDWT level has the streaming kernels' fast geometry (even origin, widths a
+    multiple of 4): the jobs that qualify for 16-bit sub-bands"""
+    out = []
+    for (w, h, nl, kw) in [(256, 192, 4, {}), (512, 256, 5, {}), (64, 48, 2, {}), (384, 160, 3, dict(cb=(5, 5))),
+                           (256, 128, 3, dict(tile=(128, 64))), (320, 200, 1, {})]:
+        img = vecgen.synth_image(w, h, 3, seed=w + h, noise=10)
+        out.append(((w, h, nl), img, vecgen.encode(img, mct=1, nlevels=nl, **kw)))
+    # flat areas: blocks without any pass are zero-filled by the block decoder
+    img = [np.where(np.add.outer(np.arange(192), np.arange(256)) < 200, 90, c).astype(np.int32) for c in vecgen.synth_image(256, 192, 3, seed=3)]
+    out.append(((256, 192, 4), img, vecgen.encode(img, mct=1, nlevels=4)))
+    return out
+
+
+def test_coef16_jobs_match_int32_jobs_and_the_oracle(dec, orc):
+    """reversible rgb24 jobs keep their sub-bands as int16 between k_ht_decode and the IDWT (every band has
+    M_b <= 15, so every coefficient fits): same pixels as the int32 layout, as the oracle, and as the source"""
+    for key, img, data in _coef16_streams():
+        info_o, planes_o, _ = orc.decode(data)
+        res = {}
+        for knob in (1, 0):
+            dec.set_int("coef16", knob)
+            job = dec.job().parse_batch([data, data]).upload().run().wait()
+            assert job.coef16() == bool(knob), (key, knob)
+            assert job.block_errors() == 0
+            res[knob] = [job.download_frame(f)[1] for f in range(2)]
+            job.free()
+        dec.set_int("coef16", 1)
+        for f in range(2):
+            for a, b, c in zip(res[1][f], res[0][f], planes_o):
+                assert np.array_equal(a, b) and np.array_equal(a, c), key
+        assert np.array_equal(res[1][0][0].reshape(info_o.height, info_o.width, 3), np.stack(img, -1)), key
+
+
+def test_coef16_is_not_used_where_it_does_not_apply(dec, orc):
+    """odd geometry, deeper samples, 9/7, refinement passes, Part-1 blocks, staged runs: int32 sub-bands as before"""
+    for name in ("rgb_mct", "rgb10_mct", "rgb_97_ict", "rgb_3passes_cb32", "p1_rgb_mct", "gray_l5_cb64"):
+        data, kw = streams.get(name)
+        job = dec.job().parse_batch([data]).upload().run().wait()
+        assert not job.coef16(), name
+        job.free()
+    key, img, data = _coef16_streams()[0]
+    job = dec.job().parse_batch([data]).upload()
+    job.run(1)
+    job.run(6)
+    job.wait()
+    assert not job.coef16()
+    info, planes = job.download_frame(0)
+    assert np.array_equal(planes[0].reshape(192, 256, 3), np.stack(img, -1))
+    job.free()
+
+
+def test_coef16_rejected_block_is_zeroed(dec, orc):
+    key, img, data = _coef16_streams()[0]
+    bad = bytearray(data)
+    bad[-3] = 0xFF                                               # the last block's Scup becomes invalid
+    info_o, planes_o, _ = orc.decode(bytes(bad))
+    assert orc.block_errors() == 1
+    job = dec.job().parse_batch([bytes(bad)]).upload().run().wait()
+    assert job.coef16() and job.block_errors() == 1
+    info, planes = job.download_frame(0)
+    assert np.array_equal(planes[0], planes_o[0])
+    job.free()
+
+
 # ---------------------------------------------------------------- Part-1 (MQ-coded) blocks: k_mq_decode
 OPJ = np.load(os.path.join(HERE, "golden", "opj_part1.npz"))
 
