@@ -10,11 +10,16 @@ import streams, bench
 
 dec = m.Decoder()
 names = [n for n in sorted(streams.CASES) if not streams.get(n)[1]]
-pk = [streams.get(n)[0] for n in names] + bench.make_streams(2, 0)
+import vecgen
+# frames that qualify for 16-bit sub-bands (8-bit RGB, even geometry), several times over so that whole batches of them occur
+c16 = [vecgen.encode(vecgen.synth_image(256, 192, 3, seed=40 + i), mct=1, nlevels=4) for i in range(3)]
+pk = [streams.get(n)[0] for n in names] + bench.make_streams(2, 0) + c16 * 8
 ref = []
+dec.set_int("coef16", 0)                      # the references with int32 sub-bands, the pipeline with the default
 for p in pk:
     info, planes, _, st = dec.decode(p)
     ref.append([zlib.crc32(a.tobytes()) for a in planes])
+dec.set_int("coef16", 1)
 rng = np.random.default_rng(7)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 order = rng.integers(0, len(pk), N)
