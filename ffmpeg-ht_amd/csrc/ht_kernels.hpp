@@ -400,6 +400,168 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
     return __any(err) ? HT_ERR_INVALID : 0;
 }
 
+/* ================================================================== k_ht_decode_pair
+ * MagSgn + dequantisation of TWO codeblocks per wavefront, one LANE PER QUAD (lanes 0-31: block 2 g, lanes 32-63:
+ * block 2 g + 1 of the table).  In k_ht_decode<true> a lane owns one sample column, so the two lanes of a quad both
+ * do the quad's work (symbol fields, kappa from the row above, U, the error test: about a quarter of the kernel's
+ * instructions, and the kernel is bound by instruction issue).  Here that work is done once per quad and a lane
+ * cuts its quad's four samples out of one 128-bit LDS window.  Only for what the bench-critical case needs -- jobs
+ * with 16-bit sub-bands (htj2k_device.hip: reversible 5/3, cleanup pass only, M_b <= 15, step 1, no ROI shift) whose
+ * blocks all have an even width of at most 64 columns -- everything else goes through k_ht_decode<true>.
+ * Same arithmetic as ht_magsgn_rows_narrow (jpeg2000htdec.c:855-885 kappa, :395-427 mu/E, jpeg2000dec.c:2120-2151). */
+__device__ __forceinline__ uint32_t half_incl_scan_u32(uint32_t v)   /* inclusive prefix sum inside each 32-lane half */
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);          /* row_bcast15 into rows 1 and 3 */
+    return (uint32_t)x;
+}
+
+__global__ void __launch_bounds__(64)
+k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+                 uint32_t *__restrict__ coef, int *__restrict__ status, uint32_t ms_words,
+                 const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t *ms_all = (uint32_t *)smem;                     /* [2][ms_words + 4] */
+    const int lane = threadIdx.x, hf = lane >> 5, q = lane & 31;
+    const uint32_t mspitch = ms_words + 4;
+    bool ok_h[2] = { false, false };
+    uint32_t lastwi_h[2] = { 0, 0 };
+
+    /* ---- per block, whole wave: checks, zero-fill of blocks without passes, MagSgn un-stuffing into LDS ---- */
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++) {
+        const int bidx = 2 * (int)blockIdx.x + hb;
+        if (bidx >= nblocks) continue;
+        const J2kBlock b = blocks[bidx];
+        uint16_t *dst16 = (uint16_t *)coef + b.plane_off;
+        if (b.npasses == 0) {
+            ht_zero_window16(dst16, b.w, b.h, b.stride, lane);
+            continue;
+        }
+        const int rem = b.npasses % 3, num_plhd = rem ? b.npasses - rem : b.npasses - 3;
+        const int S_blk = (num_plhd / 3 + b.zbp) & 0xFF, maxbp = S_blk + 1;
+        const uint32_t Lcup = b.lcup;
+        const uint8_t *D = bytes + b.data_off;
+        int err = 0;
+        uint32_t Scup = 0, Pcup = 0;
+        if (Lcup < 2) err = HT_ERR_INVALID;
+        if (!err) {
+            Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+            if (Scup < 2 || Scup > Lcup || Scup > 4079) err = HT_ERR_INVALID;
+            Pcup = Lcup - Scup;
+        }
+        if (!err && maxbp >= 32) err = HT_ERR_INVALID;
+        if (!err && (Pcup * 8 + 31) / 32 + 3 > ms_words) err = HT_ERR_INVALID;
+        if (err) {
+            ht_zero_window16(dst16, b.w, b.h, b.stride, lane);
+            if (lane == 0) status[bidx] = err;
+            continue;
+        }
+        uint32_t *ms = ms_all + hb * mspitch;
+        const uint32_t nms = (Pcup * 8 + 31) / 32 + 2;
+        for (uint32_t i = lane; i <= nms + 1; i += 64) ms[i] = 0;
+        __syncthreads();
+        const uint32_t ms_total = ht_unstuff_magsgn(D, Pcup, ms, lane);
+        __syncthreads();
+        for (uint32_t i = lane; i <= nms + 1; i += 64) {     /* past the end the MagSgn stream is all ones (:207-221) */
+            if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
+            else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
+        }
+        ok_h[hb] = true;
+        lastwi_h[hb] = nms - 2;                              /* words last_wi .. last_wi + 3 exist and are ones past the end */
+    }
+    __syncthreads();
+    if (!ok_h[0] && !ok_h[1]) return;
+
+    /* ---- both blocks in lockstep: this lane's block ---- */
+    const int bi = min(2 * (int)blockIdx.x + hf, nblocks - 1);
+    const J2kBlock b = blocks[bi];
+    const bool ok = hf ? ok_h[1] : ok_h[0];
+    const int w = b.w, h = b.h, stride = b.stride, M_b = b.M_b;
+    const int qw = (w + 1) >> 1, qh = ok ? (h + 1) >> 1 : 0;
+    const int rem = b.npasses % 3, num_plhd = rem ? b.npasses - rem : b.npasses - 3;
+    const int S_blk = (num_plhd / 3 + b.zbp) & 0xFF;
+    const int pLSB = (30 - S_blk) & 0xFF, maxbp = S_blk + 1, dshift = 31 - M_b;
+    const uint32_t halfbit = 1u << ((pLSB - 1) & 31);
+    const uint32_t *ms = ms_all + hf * mspitch;
+    const uint32_t last_wi = hf ? lastwi_h[1] : lastwi_h[0];
+    const bool act = ok && q < qw;
+    const int qwp = (int)ht_qsym_pitch((uint32_t)w);
+    const uint32_t *qp = qsym + qoff[bi] + q;
+    uint16_t *prow = (uint16_t *)coef + b.plane_off + 2 * q;     /* this quad's two columns, row 2 * row */
+    const int rows = max(__builtin_amdgcn_readlane(qh, 0), __builtin_amdgcn_readlane(qh, 32));
+    uint32_t qi_next = (act && qh > 0) ? *qp : 0u;
+    uint32_t E1p = 0, E3p = 0, ms_pos = 0;
+    int err = 0;
+    for (int row = 0; row < rows; row++) {
+        const bool arow = act && row < qh;
+        const uint32_t qi = qi_next;
+        qp += qwp;
+        qi_next = (act && row + 1 < qh) ? *qp : 0u;
+        const uint32_t rho = qi & 0xF, ek = (qi >> 4) & 0xF, e1 = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+        int kappa = 1;
+        if (row > 0) {
+            /* exponents of the row above at columns 2q-1 .. 2q+2: the neighbours' come by DPP, nothing crosses the
+             * boundary between the two blocks (lanes 31 | 32) */
+            uint32_t l = ht_dpp_left(E3p), r = ht_dpp_right(E1p);
+            l = q == 0 ? 0u : l;
+            r = q == 31 ? 0u : r;
+            const int me = (int)max(max(E1p, E3p), max(l, r));
+            kappa = (rho & (rho - 1)) ? max(me - 1, 1) : 1;
+        }
+        const int U = kappa + (int)uq;
+        if (arow && U > maxbp) err = 1;
+        const int m0 = __mul24((int)(rho & 1), U) - (int)(ek & 1), m1 = __mul24((int)((rho >> 1) & 1), U) - (int)((ek >> 1) & 1);
+        const int m2 = __mul24((int)((rho >> 2) & 1), U) - (int)((ek >> 2) & 1), m3 = __mul24((int)((rho >> 3) & 1), U) - (int)((ek >> 3) & 1);
+        const uint32_t n0 = (uint32_t)max(m0, 0), n1 = (uint32_t)max(m1, 0), n2 = (uint32_t)max(m2, 0), n3 = (uint32_t)max(m3, 0);
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        const uint32_t incl = half_incl_scan_u32(tot);
+        const uint32_t pos = ms_pos + incl - tot;
+        const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        ms_pos += hf ? end1 : end0;
+        /* every sample cuts its bits out of the two LDS words they start in (no register window: selecting the word
+         * pair of a sample by a per-lane index makes the compiler put the window into scratch memory) */
+        auto cut = [&](uint32_t p, uint32_t n) -> uint32_t {
+            const uint32_t i = min(p >> 5, last_wi + 2);
+            return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(ms[i + 1], ms[i], p), 0u, n);
+        };
+        const uint32_t p1 = pos + n0, p2 = p1 + n1, p3 = p2 + n2;
+        uint32_t v0 = cut(pos, n0), v1 = cut(p1, n1), v2 = cut(p2, n2), v3 = cut(p3, n3);
+        v0 += (e1 & 1) << n0; v1 += ((e1 >> 1) & 1) << n1; v2 += ((e1 >> 2) & 1) << n2; v3 += ((e1 >> 3) & 1) << n3;
+        E1p = m1 != 0 ? (uint32_t)(32 - __clz((int)(v1 | 1))) : 0u;      /* bottom-left and bottom-right feed the next row */
+        E3p = m3 != 0 ? (uint32_t)(32 - __clz((int)(v3 | 1))) : 0u;
+        auto sample = [&](uint32_t v, int m) -> uint32_t {               /* mu (:407-427) -> dequantization_int, 16 bits */
+            const uint32_t mu = ((((v >> 1) + 1) << pLSB) | halfbit) & 0x7FFFFFFFu;
+            int r = (int)(mu >> dshift);
+            const int sg = -(int)(v & 1);
+            r = (r ^ sg) - sg;
+            return (uint32_t)(m != 0 ? r : 0) & 0xFFFFu;
+        };
+        const uint32_t top = sample(v0, m0) | sample(v2, m2) << 16, bot = sample(v1, m1) | sample(v3, m3) << 16;
+        const bool two = 2 * row + 1 < h;
+        /* exactly two stores per row, as in ht_magsgn_rows_narrow */
+        *(arow ? (uint32_t *)prow : sink) = top;
+        *((arow && two) ? (uint32_t *)(prow + stride) : sink) = bot;
+        prow += 2 * stride;
+    }
+    /* a block whose U ran past maxbp is rejected as a whole (:862-868): zero it, whole wave per block */
+    const bool e0 = __ballot(err && hf == 0) != 0, e1b = __ballot(err && hf == 1) != 0;
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++) {
+        if (!(hb ? e1b : e0)) continue;
+        const int bidx = 2 * (int)blockIdx.x + hb;
+        const J2kBlock bb = blocks[bidx];
+        __syncthreads();
+        ht_zero_window16((uint16_t *)coef + bb.plane_off, bb.w, bb.h, bb.stride, lane);
+        if (lane == 0) status[bidx] = HT_ERR_INVALID;
+    }
+}
+
 /* EXTERNAL_VLC = false: the whole block in this kernel (stage 1 on lane 0).
  * EXTERNAL_VLC = true : stage 1 was done by k_ht_vlc (one LANE per codeblock, 64 serial decodes
  *                       per wavefront); the packed quad symbols come from `qsym` (qoff[b] is the

@@ -82,6 +82,7 @@ struct htj2k_ctx {
     int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = LDS + register/DPP tile kernel,
                                         * 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
+    int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
     int coef16 = 1;                    /* 1: reversible jobs whose coefficients fit 16 bits keep them as int16_t between the
                                         * block decoder and the IDWT (see coef16_ok) */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
@@ -131,6 +132,7 @@ struct htj2k_job {
     /* every sample the block decoder writes fits int16_t and only the FASTONLY streaming IDWT kernels read them: all
      * planes coded, reversible 5/3 with at least one level, all blocks HT cleanup-only, <= 64 columns, M_b <= 15,
      * step size 1, no ROI shift, all levels of fast geometry.  The sub-bands then travel as 2 bytes per sample. */
+    bool pair_ok = false;              /* ... and k_ht_decode_pair's dword stores are aligned: even widths, strides, offsets */
     bool coef16_ok = false;
     bool coef_is16 = false;            /* what the last HT stage run actually wrote */
     int nht = 0;
@@ -268,6 +270,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
     return HTJ2K_ERR_EINVAL;
@@ -914,6 +917,11 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
         for (size_t i = 0; ok && i < j->tile_fusable.size(); i++) ok = j->tile_fusable[i] != 0;
         j->coef16_ok = ok;
+        for (size_t i = 0; ok && i < j->blocks.size(); i++) {
+            const J2kBlock &b = j->blocks[i];
+            ok = !(b.w & 1) && !(b.stride & 1) && !(b.plane_off & 1);
+        }
+        j->pair_ok = ok;
     }
     if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
@@ -1132,6 +1140,13 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                        (const uint8_t *)j->d_bytes.p, (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
                                        (uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
+                if (j->coef_is16 && j->pair_ok && c->ht_pair)
+                    hipLaunchKernelGGL(k_ht_decode_pair, dim3((nblocks + 1) / 2), dim3(64), 2 * (j->lds_ext.ms_words + 4) * 4, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                       (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words,
+                                       (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                       (uint32_t *)j->d_coef.p + j->nsamples + 32);
+                else
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,

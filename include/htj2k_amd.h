@@ -214,6 +214,7 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
  *   "coef16"      1 (default): jobs that qualify keep the sub-bands as 16-bit samples (htj2k_job_coef16)
+ *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
  *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
  *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);

@@ -375,18 +375,22 @@ def test_coef16_jobs_match_int32_jobs_and_the_oracle(dec, orc):
     for key, img, data in _coef16_streams():
         info_o, planes_o, _ = orc.decode(data)
         res = {}
-        for knob in (1, 0):
-            dec.set_int("coef16", knob)
-            job = dec.job().parse_batch([data, data]).upload().run().wait()
-            assert job.coef16() == bool(knob), (key, knob)
+        # (coef16, ht_pair): 16-bit sub-bands with k_ht_decode_pair (two blocks per wave, the default where it applies),
+        # with k_ht_decode<true>, and the int32 layout
+        for knob in ((1, 1), (1, 0), (0, 1)):
+            dec.set_int("coef16", knob[0])
+            dec.set_int("ht_pair", knob[1])
+            job = dec.job().parse_batch([data, data, data]).upload().run().wait()
+            assert job.coef16() == bool(knob[0]), (key, knob)
             assert job.block_errors() == 0
-            res[knob] = [job.download_frame(f)[1] for f in range(2)]
+            res[knob] = [job.download_frame(f)[1] for f in range(3)]
             job.free()
         dec.set_int("coef16", 1)
-        for f in range(2):
-            for a, b, c in zip(res[1][f], res[0][f], planes_o):
-                assert np.array_equal(a, b) and np.array_equal(a, c), key
-        assert np.array_equal(res[1][0][0].reshape(info_o.height, info_o.width, 3), np.stack(img, -1)), key
+        dec.set_int("ht_pair", 1)
+        for f in range(3):
+            for a, b, c, d in zip(res[(1, 1)][f], res[(1, 0)][f], res[(0, 1)][f], planes_o):
+                assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d), key
+        assert np.array_equal(res[(1, 1)][0][0].reshape(info_o.height, info_o.width, 3), np.stack(img, -1)), key
 
 
 def test_coef16_is_not_used_where_it_does_not_apply(dec, orc):
