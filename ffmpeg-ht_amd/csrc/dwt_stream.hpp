@@ -20,6 +20,9 @@
  * HALO rows above and below the strip) and every output written once.  The final level of an
  * RGB frame moves 4 + 1 bytes per sample instead of the 4 + 4 (IDWT) + 4 + 1 (MCT/pack
  * kernel) of the unfused pipeline.
+ * Where every coefficient of a job provably fits 16 bits (reversible 5/3, M_b <= 15 in every band:
+ * C16 / LL16 below, decided in htj2k_device.hip) the sub-bands the block decoder wrote are read as
+ * 16-bit pairs and widened in registers: 2.5 + 1 bytes per sample at the final level.
  *
  * Boundaries: as in k_idwt_tile2, positions outside the line are fetched through the
  * whole-sample symmetric reflection (LineMap::idx), which is bit-identical to the reference's

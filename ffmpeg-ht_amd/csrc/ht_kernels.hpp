@@ -22,6 +22,9 @@
  *                       predictor kappa from the row above (:855-885), m_n, wave prefix sum ->
  *                       MagSgn bit offsets, extraction from the LDS bit array, mu/E (:395-427),
  *                       refinement bits, dequantisation and two coalesced row stores.
+ *                       k_ht_decode_pair: the same for two blocks per wave with one lane per quad
+ *                       (the quad-level work is not done twice), for jobs whose sub-bands are
+ *                       stored as 16-bit samples (htj2k_device.hip: coef16).
  *
  * k_ht_decode<false> is the first correct version (everything in one kernel, the serial stages on
  * lane 0), kept as a fallback and A/B reference; its LDS layout is HtLds.
