@@ -1332,7 +1332,12 @@ __host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
 {
     return 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES + (size_t)((((max_qw + 3) >> 2) | 1) << 2) * 64;
 }
+/* NARROW (every block of the launch at most 32 quads = 64 columns wide): the row-above significance a context
+ * needs is two bits per quad and lives in two registers, and the flush bookkeeping is fetched from the owning lane
+ * with ds_bpermute: 16 256 bytes of LDS, 10 instead of 8 waves per CU for this latency-bound kernel */
+#define HT_VLC_LDS_NARROW (4096 + 640 + HT_VSTAGE_BYTES + 64 * HT_VLC_OUT_PITCH * 4)
 
+template <bool NARROW>
 __global__ void __launch_bounds__(64)
 k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
          const uint16_t *__restrict__ g_tables, uint32_t *__restrict__ qsym,
@@ -1345,17 +1350,17 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     /* VLC words of every lane staged through LDS: 24 dwords (96 contiguous bytes) per lane are
      * fetched once every 8 quad pairs and cover the 16 pairs after they are issued (16 x 38 bits
      * + 31 < 768), so a lane touches 1-2 cache lines per refill instead of per pair */
-    uint32_t *vstage = (uint32_t *)(smem + 4096 + 1024);
+    uint32_t *vstage = (uint32_t *)(smem + 4096 + (NARROW ? 640 : 1024));
     /* output stage: the two quad symbols of a pass go to LDS; every 8 passes the wave writes the 64
      * lanes' 64-byte chunks out together, 4 lanes per chunk with 16-byte stores.  A lane storing
      * its own two dwords per pass made 128 separate line requests per pass and wave (every lane
      * writes into a different block's symbol array): that address traffic, not arithmetic, was
      * 40 % of this kernel's time. */
-    uint32_t *ostage = (uint32_t *)(smem + 4096 + 1024 + HT_VSTAGE_BYTES);
-    uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;
+    uint32_t *ostage = (uint32_t *)(smem + 4096 + (NARROW ? 640 : 1024) + HT_VSTAGE_BYTES);
+    uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;   /* !NARROW only */
     /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
      * dwords is odd so the 64 lanes hit distinct banks */
-    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;
+    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;                            /* !NARROW only */
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int lane = threadIdx.x;
     const int bi = blockIdx.x * 64 + lane;
@@ -1389,9 +1394,12 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     int max_it = n_it;
 #pragma unroll
     for (int o = 32; o; o >>= 1) max_it = max(max_it, __shfl_xor(max_it, o));
-    obase_lo[lane] = (uint32_t)(uintptr_t)qout;
-    obase_hi[lane] = (uint32_t)((uintptr_t)qout >> 32);
-    onit[lane] = (uint32_t)n_it;
+    const uint32_t my_lo = (uint32_t)(uintptr_t)qout, my_hi = (uint32_t)((uintptr_t)qout >> 32);
+    if (!NARROW) {
+        obase_lo[lane] = my_lo;
+        obase_hi[lane] = my_hi;
+        onit[lane] = (uint32_t)n_it;
+    }
     __syncthreads();
 
     const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
@@ -1422,18 +1430,25 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             const int c = 16 * p + (lane >> 2), part = lane & 3;
             const uint32_t *src = ostage + c * HT_VLC_OUT_PITCH + 4 * part;
             const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-            uint32_t *dst = (uint32_t *)(((uintptr_t)obase_hi[c] << 32) | obase_lo[c]) + (size_t)win * 16 + 4 * part;
+            /* the symbol array and pass count of the lane that owns chunk c */
+            const uint32_t c_lo = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_lo) : obase_lo[c];
+            const uint32_t c_hi = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_hi) : obase_hi[c];
+            const uint32_t c_nit = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, n_it) : onit[c];
+            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * 16 + 4 * part;
             /* chunks of lanes that are done (or never had a block) go to a scratch line: always four
              * stores, so that the wait for the staged VLC words can be counted (vmcnt) */
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(1))) u32x4 g_u32x4;    /* a global, not a FLAT, store */
             u32x4 vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
-            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * 8) < onit[c] ? dst : sink + 4 * part) = vv;
+            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * 8) < c_nit ? dst : sink + 4 * part) = vv;
         }
     };
 
     int ctx_run = 0, row = 0, qx = 0;
     int rho_left = 0, ral = 0, ra_next = 0;
+    /* NARROW: bit q of A1 / A3 = bit 1 / bit 3 of the significance pattern of quad q in the row above (the two samples
+     * of its lower row: all a context looks at, jpeg2000htdec.c:725-760); N1 / N3 collect the current row */
+    uint32_t A1 = 0, A3 = 0, N1 = 0, N3 = 0;
     for (int t = 0; t < max_it; t++) {
         const bool active = t < n_it;
         const uint16_t *table = tbl + (row ? 1024 : 0);
@@ -1485,11 +1500,20 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         for (int k = 0; k < 2; k++) {
             const bool en = active && (k == 0 || pair);
             const int q = qx + k;
-            const int ra = ra_next;
-            const int rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
-            const int ctx = row0 ? ctx_run
-                                 : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
-                                    ((((ra >> 3) | (rar >> 1)) & 1) << 2));
+            int ra, rar, ctx;
+            if (NARROW) {
+                const uint32_t a1 = q ? A1 >> (q - 1) : A1 << 1, a3 = q ? A3 >> (q - 1) : A3 << 1;   /* bit 0: quad q-1, bit 1: q, bit 2: q+1 */
+                ra = 0; rar = 0;
+                ctx = row0 ? ctx_run
+                           : (int)((((a1 >> 1) | a3) & 1) | ((((uint32_t)rho_left >> 2) | ((uint32_t)rho_left >> 3)) & 1) << 1 |
+                                   (((a3 >> 1) | (a1 >> 2)) & 1) << 2);
+            } else {
+                ra = ra_next;
+                rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
+                ctx = row0 ? ctx_run
+                           : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
+                              ((((ra >> 3) | (rar >> 1)) & 1) << 2));
+            }
             const bool mq = en && ctx == 0;
             const int msym = (int)(m & 1);
             m >>= mq ? 1 : 0; mused += mq ? 1 : 0;
@@ -1502,6 +1526,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 rho_left = rho[k];
                 ral = ra;
                 ra_next = rar;
+                if (NARROW) { N1 |= (((uint32_t)rho[k] >> 1) & 1u) << q; N3 |= (((uint32_t)rho[k] >> 3) & 1u) << q; }
                 ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
             }
         }
@@ -1533,8 +1558,10 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         if (active) {
             vpos += aused + uused;
             msyms >>= mused; mcnt -= (int)mused;
-            myrho[qx] = (uint8_t)rho[0];
-            if (pair) myrho[qx + 1] = (uint8_t)rho[1];
+            if (!NARROW) {
+                myrho[qx] = (uint8_t)rho[0];
+                if (pair) myrho[qx + 1] = (uint8_t)rho[1];
+            }
         }
         ost[2 * (t & 7)] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
         ost[2 * (t & 7) + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
@@ -1543,7 +1570,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         if (active && qx >= qw) {
             qx = 0; row++;
             rho_left = 0; ral = 0;
-            ra_next = (int)myrho[0];                     /* above quad 0 of the new row */
+            if (NARROW) { A1 = N1; A3 = N3; N1 = 0; N3 = 0; }
+            else ra_next = (int)myrho[0];                /* above quad 0 of the new row */
         }
     }
     if (max_it > 0) flush((max_it - 1) >> 3);

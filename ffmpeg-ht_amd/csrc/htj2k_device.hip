@@ -1114,13 +1114,14 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         }
         j->coef_is16 = false;
         if (nblocks) {
-            const size_t vlc_lds = ht_vlc_lds_bytes(j->max_qw);
+            const bool vlc_narrow = j->max_qw <= 32;               /* no block wider than 64 columns: k_ht_vlc<true> */
+            const size_t vlc_lds = vlc_narrow ? (size_t)HT_VLC_LDS_NARROW : ht_vlc_lds_bytes(j->max_qw);
             /* 16-bit sub-bands only when this very call also runs the (fused, streaming) IDWT that reads them */
             j->coef_is16 = c->coef16 && j->coef16_ok && c->ht_mode == 1 && vlc_lds <= 160 * 1024 && mask == 7 &&
                            c->idwt_mode == 3 && c->fuse_pack;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
@@ -1130,7 +1131,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
-                hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
+                hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads + 32);
@@ -1712,7 +1713,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     const size_t vlc_lds = ht_vlc_lds_bytes(tmp.lds.max_qw);
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
-            e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
+            e = hipFuncSetAttribute((const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
         if (e == hipSuccess && (int)tmp.ext.total > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
@@ -1722,7 +1723,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                 (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
             hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
-            hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
+            hipLaunchKernelGGL(k_ht_vlc<false>, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq + 32);
             if (!reflist.empty())
