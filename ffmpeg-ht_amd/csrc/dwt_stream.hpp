@@ -125,7 +125,9 @@ struct DwtFusedArgs {
 /* C16: the sub-bands the block decoder wrote are 16-bit samples (the coefficient buffer read as int16_t with the same
  * element offsets; reversible 5/3 planes whose bands all have M_b <= 15, see htj2k_device.hip); LL16: so is the LL band,
  * i.e. this is the first level.  Both only on the FAST path (aligned sample pairs). */
-template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false>
+/* OUTK: what the FAST && FUSED store writes per lane and row (four pixel columns): 0 rgb24 (three 8-bit components
+ * interleaved, 12 bytes), 1 rgb48 (three 16-bit components interleaved, 24 bytes), 2 one 8-bit plane (4 bytes) */
+template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
@@ -258,20 +260,22 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     int f_ls = 0, f_dc[3] = { 0, 0, 0 }, f_hi[3] = { 0, 0, 0 }, f_sh[3] = { 0, 0, 0 };
     bool f_mct = false;
     if (FAST && FUSED) {
-        const PackComp &C0 = T->c[0];
+        const PackComp &C0 = T->c[OUTK == 2 ? comp0 : 0];
         f_ls = T->out.linesize[C0.out_plane];
-        f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * 3;
-        f_mct = T->mct != 0;
+        f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * (OUTK == 0 ? 3 : OUTK == 1 ? 6 : 1);
+        f_mct = OUTK != 2 && T->mct != 0;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            f_dc[c] = 1 << (T->c[c].cbps - 1);
-            f_hi[c] = (1 << T->c[c].cbps) - 1;
-            f_sh[c] = T->precision - T->c[c].cbps;
+        for (int c = 0; c < (OUTK == 2 ? 1 : 3); c++) {
+            const PackComp &C = T->c[OUTK == 2 ? comp0 : c];
+            f_dc[c] = 1 << (C.cbps - 1);
+            f_hi[c] = (1 << C.cbps) - 1;
+            f_sh[c] = T->precision - C.cbps;
         }
     }
     const bool lane_ok = lane >= 1 && xa + 4 <= x_hi;     /* FAST: the quadruple is wholly inside the strip */
 
-    uint32_t wk[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };       /* fast fused path: the two rows' store data ... */
+    constexpr int NW = OUTK == 0 ? 3 : OUTK == 1 ? 6 : 1;   /* dwords a lane stores per row */
+    uint32_t wk[2][6] = { { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0, 0 } };   /* fast fused path: the two rows' store data ... */
     uintptr_t ak[2] = { 0, 0 };                              /* ... and addresses of the last step */
     auto emit = [&](int row_abs, uint32_t (&val)[NC][4], int slot) {
         const int y = row_abs - g.mv;
@@ -295,16 +299,17 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 for (int c = 0; c < 4; c++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[c][k] = c < NC ? (int)val[c < NC ? c : 0][k] : 0;
+                constexpr int NO = OUTK == 2 ? 1 : 3;               /* components this store writes */
                 if (f_mct) {
                     pack_mct(TYPE, v);
                 } else if (TYPE == J2K_DWT97) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++)
+                    for (int c = 0; c < NO; c++)
 #pragma unroll
                         for (int k = 0; k < 4; k++) v[c][k] = __float2int_rn(__int_as_float(v[c][k]));
                 }
 #pragma unroll
-                for (int c = 0; c < 3; c++)
+                for (int c = 0; c < NO; c++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[c][k] = min(max(v[c][k] + f_dc[c], 0), f_hi[c]) << f_sh[c];
                 /* the frame pointer comes out of a descriptor: say that it is global memory, or the
@@ -312,13 +317,28 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
                 typedef __attribute__((address_space(1))) u32x3_a4 g_u32x3;
-                u32x3 w;
-                w.x = (uint32_t)v[0][0] | ((uint32_t)v[1][0] << 8) | ((uint32_t)v[2][0] << 16) | ((uint32_t)v[0][1] << 24);
-                w.y = (uint32_t)v[1][1] | ((uint32_t)v[2][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[1][2] << 24);
-                w.z = (uint32_t)v[2][2] | ((uint32_t)v[0][3] << 8) | ((uint32_t)v[1][3] << 16) | ((uint32_t)v[2][3] << 24);
                 const uintptr_t addr = (uintptr_t)(f_dst + (size_t)y * f_ls);
-                if (lane_ok) *(g_u32x3 *)addr = w;
-                wk[slot][0] = w.x; wk[slot][1] = w.y; wk[slot][2] = w.z; ak[slot] = addr;
+                if (OUTK == 0) {
+                    u32x3 w;
+                    w.x = (uint32_t)v[0][0] | ((uint32_t)v[1][0] << 8) | ((uint32_t)v[2][0] << 16) | ((uint32_t)v[0][1] << 24);
+                    w.y = (uint32_t)v[1][1] | ((uint32_t)v[2][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[1][2] << 24);
+                    w.z = (uint32_t)v[2][2] | ((uint32_t)v[0][3] << 8) | ((uint32_t)v[1][3] << 16) | ((uint32_t)v[2][3] << 24);
+                    if (lane_ok) *(g_u32x3 *)addr = w;
+                    wk[slot][0] = w.x; wk[slot][1] = w.y; wk[slot][2] = w.z;
+                } else if (OUTK == 1) {                              /* r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3, 16 bits each */
+                    u32x3 w0, w1;
+                    w0.x = (uint32_t)v[0][0] | ((uint32_t)v[1][0] << 16); w0.y = (uint32_t)v[2][0] | ((uint32_t)v[0][1] << 16);
+                    w0.z = (uint32_t)v[1][1] | ((uint32_t)v[2][1] << 16); w1.x = (uint32_t)v[0][2] | ((uint32_t)v[1][2] << 16);
+                    w1.y = (uint32_t)v[2][2] | ((uint32_t)v[0][3] << 16); w1.z = (uint32_t)v[1][3] | ((uint32_t)v[2][3] << 16);
+                    if (lane_ok) { *(g_u32x3 *)addr = w0; *(g_u32x3 *)(addr + 12) = w1; }
+                    wk[slot][0] = w0.x; wk[slot][1] = w0.y; wk[slot][2] = w0.z; wk[slot][3] = w1.x; wk[slot][4] = w1.y; wk[slot][5] = w1.z;
+                } else {
+                    typedef __attribute__((address_space(1))) uint32_t g_u32;
+                    const uint32_t w = (uint32_t)v[0][0] | ((uint32_t)v[0][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[0][3] << 24);
+                    if (lane_ok) *(g_u32 *)addr = w;
+                    wk[slot][0] = w;
+                }
+                ak[slot] = addr;
             }
             return;
         }
@@ -419,9 +439,11 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         /* the registers of the last step's store data stay allocated until the next loads are
          * out: rewriting them earlier costs a wait for those stores (and, vmcnt being in order,
          * for every load issued before them) */
-        if (FAST && FUSED)
-            asm volatile("" : : "v"(wk[0][0]), "v"(wk[0][1]), "v"(wk[0][2]), "v"(wk[1][0]), "v"(wk[1][1]), "v"(wk[1][2]),
-                                "v"(ak[0]), "v"(ak[1]));
+        if (FAST && FUSED) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) asm volatile("" : : "v"(wk[0][i]), "v"(wk[1][i]));
+            asm volatile("" : : "v"(ak[0]), "v"(ak[1]));
+        }
     };
     for (int ye = s_first;; ye += 4 * dir) {
         load_rows(ye + 2 * dir, LB, HB);
@@ -456,14 +478,39 @@ __host__ __device__ inline bool stream_fast_rgb24(const PackTile &T, const DwtLe
            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
 }
 
-template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false>
+/* which fast store a component group qualifies for: 0 rgb24, 1 rgb48, 2 one 8-bit plane; -1 none (general path) */
+__host__ __device__ inline int stream_fast_outk(const PackTile &T, const DwtLevel &g, int ncomp_group, int comp0)
+{
+    if (stream_fast_rgb24(T, g, ncomp_group, comp0)) return 0;
+    const OutPlanes &O = T.out;
+    if (ncomp_group == 3 && T.ncomp == 3 && comp0 == 0 && T.out_bytes == 2) {
+        const PackComp &C0 = T.c[0];
+        const int pl = C0.out_plane;
+        if (C0.pix_step == 3 && T.c[0].pix_off == 0 && T.c[1].pix_off == 1 && T.c[2].pix_off == 2 &&
+            T.precision <= 16 && T.c[0].cbps <= T.precision && T.c[1].cbps <= T.precision && T.c[2].cbps <= T.precision &&
+            C0.out_x >= 0 && !(C0.out_x & 3) && C0.out_y >= 0 && C0.out_x + g.lh <= O.width[pl] && C0.out_y + g.lv <= O.height[pl] &&
+            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3))
+            return 1;
+    }
+    if (ncomp_group == 1 && T.out_bytes == 1) {
+        const PackComp &C = T.c[comp0];
+        const int pl = C.out_plane;
+        if (C.pix_step == 1 && C.pix_off == 0 && T.precision == 8 && C.cbps <= 8 &&
+            C.out_x >= 0 && !(C.out_x & 3) && C.out_y >= 0 && C.out_x + g.lh <= O.width[pl] && C.out_y + g.lv <= O.height[pl] &&
+            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3))
+            return 2;
+    }
+    return -1;
+}
+
+template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
 {
     static_assert(!C16 || FASTONLY, "16-bit sub-bands: FASTONLY launches only");
     if (FASTONLY) {
-        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16, OUTK>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
     } else {                                               /* per-wave choice; all conditions are wave-uniform */
         bool fast = stream_fast_geom(A[0].g);
         if (FUSED) fast = fast && stream_fast_rgb24(*T, A[0].g, NC, comp0);
@@ -504,7 +551,7 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
-template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false>
+template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __global__ void __launch_bounds__(64)
 k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th, StreamGrid G)
@@ -515,7 +562,7 @@ k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__rest
     DwtTileArgs A[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) A[c] = F.a[c];
-    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
+    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16, OUTK>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
 }
 
 }  // namespace htj2k

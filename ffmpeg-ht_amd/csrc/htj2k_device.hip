@@ -100,6 +100,7 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
     double hbm_bytes = 0;              /* least HBM traffic: alg_bytes, or for a fused final level 4 * lh * lv read +
                                         * the frame bytes written */
     int nc = 0;                        /* 0: table of DwtTileArgs; 1/3/4: table of DwtFusedArgs (fused final level) */
+    int outk = -1;                     /* fused level: the fast store all its entries qualify for (stream_fast_outk), -1: general path */
     bool all_fast = false;             /* every entry qualifies for the streaming kernels' fast path */
 };
 
@@ -735,14 +736,25 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                     push_bytes(j->h_desc, ta.data(), ta.size() * sizeof(DwtTileArgs));
                     j->launches_fused.push_back(g);
                 }
-                for (int nc = 1; nc <= 4; nc++) {
+                /* one launch per (components in the group, fast store kind): groups whose geometry and frame qualify for
+                 * a fast store go to the FASTONLY kernel of that kind, the rest to the general kernel (outk -1) */
+                for (int nc = 1; nc <= 4; nc++)
+                for (int outk = -1; outk <= 2; outk++) {
                     LevelLaunch fz = g;
                     fz.count = 0; fz.max_lh = fz.max_lv = 0; fz.alg_bytes = 0; fz.hbm_bytes = 0; fz.min_l = 1 << 30; fz.nc = nc;
-                    fz.all_fast = true;
+                    fz.all_fast = outk >= 0;
+                    fz.outk = outk;
                     std::vector<DwtFusedArgs> fa;
                     for (const Group &gr : groups) {
                         const J2kTileComp &tc = j->tilecomps[gr.tc0];
                         if (gr.nc != nc || tc.transform != type || tc.ndeclevels - 1 != lev) continue;
+                        {
+                            const PackTile *PT0 = (const PackTile *)(j->h_desc.data() + j->pack_off) + gr.pack_tile;
+                            const DwtLevel g0 = level_args(tc, lev).g;
+                            int kind = stream_fast_geom(g0) ? stream_fast_outk(*PT0, g0, nc, gr.comp0) : -1;
+                            if (kind > 0 && type == J2K_DWT97_INT) kind = -1;      /* rgb48 / plane stores: 5/3 and 9/7 float only */
+                            if (kind != outk) continue;
+                        }
                         DwtFusedArgs A;
                         memset(&A, 0, sizeof(A));
                         for (int cc = 0; cc < nc; cc++) A.a[cc] = level_args(j->tilecomps[gr.tc0 + cc], lev);
@@ -753,7 +765,6 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                         const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + gr.pack_tile;
                         fz.alg_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * 8.0;
                         fz.hbm_bytes += (double)nc * A.a[0].g.lh * A.a[0].g.lv * (4.0 + PT->out_bytes);
-                        fz.all_fast = fz.all_fast && stream_fast_geom(A.a[0].g) && stream_fast_rgb24(*PT, A.a[0].g, nc, gr.comp0);
                     }
                     if (fa.empty()) continue;
                     fz.count = (int)fa.size();
@@ -913,7 +924,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
         for (size_t i = 0; ok && i < j->launches_fused.size(); i++) {
             const LevelLaunch &L = j->launches_fused[i];
-            ok = L.all_fast && L.type == J2K_DWT53 && L.min_l >= 2 && (L.nc == 0 || L.nc == 3);
+            ok = L.all_fast && L.type == J2K_DWT53 && L.min_l >= 2;
         }
         for (size_t i = 0; ok && i < j->tile_fusable.size(); i++) ok = j->tile_fusable[i] != 0;
         j->coef16_ok = ok;
@@ -1029,10 +1040,15 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
-    if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: nc == 3, all_fast */
-        if (L.level == 0) hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 3, true, true, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
-        else hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 3, true, true, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
-    } else if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+#define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G)
+    if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: every fused launch is a fast-store one */
+        const bool l0 = L.level == 0;
+        if (L.outk == 0) { if (l0) FUSED_FAST(3, true, true, 0); else FUSED_FAST(3, true, false, 0); }
+        else if (L.outk == 1) { if (l0) FUSED_FAST(3, true, true, 1); else FUSED_FAST(3, true, false, 1); }
+        else { if (l0) FUSED_FAST(1, true, true, 2); else FUSED_FAST(1, true, false, 2); }
+    } else if (L.outk == 1) FUSED_FAST(3, false, false, 1);
+    else if (L.outk == 2) FUSED_FAST(1, false, false, 2);
+    else if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
