@@ -126,7 +126,8 @@ struct DwtFusedArgs {
  * element offsets; reversible 5/3 planes whose bands all have M_b <= 15, see htj2k_device.hip); LL16: so is the LL band,
  * i.e. this is the first level.  Both only on the FAST path (aligned sample pairs). */
 /* OUTK: what the FAST && FUSED store writes per lane and row (four pixel columns): 0 rgb24 (three 8-bit components
- * interleaved, 12 bytes), 1 rgb48 (three 16-bit components interleaved, 24 bytes), 2 one 8-bit plane (4 bytes) */
+ * interleaved, 12 bytes), 1 rgb48 (three 16-bit components interleaved, 24 bytes), 2 one 8-bit plane (4 bytes),
+ * 3 one 16-bit plane (8 bytes) */
 template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
@@ -260,13 +261,13 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     int f_ls = 0, f_dc[3] = { 0, 0, 0 }, f_hi[3] = { 0, 0, 0 }, f_sh[3] = { 0, 0, 0 };
     bool f_mct = false;
     if (FAST && FUSED) {
-        const PackComp &C0 = T->c[OUTK == 2 ? comp0 : 0];
+        const PackComp &C0 = T->c[OUTK >= 2 ? comp0 : 0];
         f_ls = T->out.linesize[C0.out_plane];
-        f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * (OUTK == 0 ? 3 : OUTK == 1 ? 6 : 1);
-        f_mct = OUTK != 2 && T->mct != 0;
+        f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * (OUTK == 0 ? 3 : OUTK == 1 ? 6 : OUTK == 2 ? 1 : 2);
+        f_mct = OUTK < 2 && T->mct != 0;
 #pragma unroll
-        for (int c = 0; c < (OUTK == 2 ? 1 : 3); c++) {
-            const PackComp &C = T->c[OUTK == 2 ? comp0 : c];
+        for (int c = 0; c < (OUTK >= 2 ? 1 : 3); c++) {
+            const PackComp &C = T->c[OUTK >= 2 ? comp0 : c];
             f_dc[c] = 1 << (C.cbps - 1);
             f_hi[c] = (1 << C.cbps) - 1;
             f_sh[c] = T->precision - C.cbps;
@@ -274,7 +275,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     }
     const bool lane_ok = lane >= 1 && xa + 4 <= x_hi;     /* FAST: the quadruple is wholly inside the strip */
 
-    constexpr int NW = OUTK == 0 ? 3 : OUTK == 1 ? 6 : 1;   /* dwords a lane stores per row */
+    constexpr int NW = OUTK == 0 ? 3 : OUTK == 1 ? 6 : OUTK == 2 ? 1 : 2;   /* dwords a lane stores per row */
     uint32_t wk[2][6] = { { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0, 0 } };   /* fast fused path: the two rows' store data ... */
     uintptr_t ak[2] = { 0, 0 };                              /* ... and addresses of the last step */
     auto emit = [&](int row_abs, uint32_t (&val)[NC][4], int slot) {
@@ -299,7 +300,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 for (int c = 0; c < 4; c++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[c][k] = c < NC ? (int)val[c < NC ? c : 0][k] : 0;
-                constexpr int NO = OUTK == 2 ? 1 : 3;               /* components this store writes */
+                constexpr int NO = OUTK >= 2 ? 1 : 3;               /* components this store writes */
                 if (f_mct) {
                     pack_mct(TYPE, v);
                 } else if (TYPE == J2K_DWT97) {
@@ -332,11 +333,19 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                     w1.y = (uint32_t)v[2][2] | ((uint32_t)v[0][3] << 16); w1.z = (uint32_t)v[1][3] | ((uint32_t)v[2][3] << 16);
                     if (lane_ok) { *(g_u32x3 *)addr = w0; *(g_u32x3 *)(addr + 12) = w1; }
                     wk[slot][0] = w0.x; wk[slot][1] = w0.y; wk[slot][2] = w0.z; wk[slot][3] = w1.x; wk[slot][4] = w1.y; wk[slot][5] = w1.z;
-                } else {
+                } else if (OUTK == 2) {
                     typedef __attribute__((address_space(1))) uint32_t g_u32;
                     const uint32_t w = (uint32_t)v[0][0] | ((uint32_t)v[0][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[0][3] << 24);
                     if (lane_ok) *(g_u32 *)addr = w;
                     wk[slot][0] = w;
+                } else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+                    typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2;
+                    u32x2 w;
+                    w.x = (uint32_t)v[0][0] | ((uint32_t)v[0][1] << 16); w.y = (uint32_t)v[0][2] | ((uint32_t)v[0][3] << 16);
+                    if (lane_ok) *(g_u32x2 *)addr = w;
+                    wk[slot][0] = w.x; wk[slot][1] = w.y;
                 }
                 ak[slot] = addr;
             }
@@ -478,7 +487,8 @@ __host__ __device__ inline bool stream_fast_rgb24(const PackTile &T, const DwtLe
            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3);
 }
 
-/* which fast store a component group qualifies for: 0 rgb24, 1 rgb48, 2 one 8-bit plane; -1 none (general path) */
+/* which fast store a component group qualifies for: 0 rgb24, 1 rgb48, 2 one 8-bit plane, 3 one 16-bit plane; -1 none
+ * (general path) */
 __host__ __device__ inline int stream_fast_outk(const PackTile &T, const DwtLevel &g, int ncomp_group, int comp0)
 {
     if (stream_fast_rgb24(T, g, ncomp_group, comp0)) return 0;
@@ -499,6 +509,14 @@ __host__ __device__ inline int stream_fast_outk(const PackTile &T, const DwtLeve
             C.out_x >= 0 && !(C.out_x & 3) && C.out_y >= 0 && C.out_x + g.lh <= O.width[pl] && C.out_y + g.lv <= O.height[pl] &&
             !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3))
             return 2;
+    }
+    if (ncomp_group == 1 && T.out_bytes == 2) {
+        const PackComp &C = T.c[comp0];
+        const int pl = C.out_plane;
+        if (C.pix_step == 1 && C.pix_off == 0 && T.precision <= 16 && C.cbps <= T.precision &&
+            C.out_x >= 0 && !(C.out_x & 3) && C.out_y >= 0 && C.out_x + g.lh <= O.width[pl] && C.out_y + g.lv <= O.height[pl] &&
+            !(O.linesize[pl] & 3) && !(((uintptr_t)O.ptr[pl]) & 3))
+            return 3;
     }
     return -1;
 }

@@ -739,7 +739,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
                 /* one launch per (components in the group, fast store kind): groups whose geometry and frame qualify for
                  * a fast store go to the FASTONLY kernel of that kind, the rest to the general kernel (outk -1) */
                 for (int nc = 1; nc <= 4; nc++)
-                for (int outk = -1; outk <= 2; outk++) {
+                for (int outk = -1; outk <= 3; outk++) {
                     LevelLaunch fz = g;
                     fz.count = 0; fz.max_lh = fz.max_lv = 0; fz.alg_bytes = 0; fz.hbm_bytes = 0; fz.min_l = 1 << 30; fz.nc = nc;
                     fz.all_fast = outk >= 0;
@@ -1045,9 +1045,11 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
         const bool l0 = L.level == 0;
         if (L.outk == 0) { if (l0) FUSED_FAST(3, true, true, 0); else FUSED_FAST(3, true, false, 0); }
         else if (L.outk == 1) { if (l0) FUSED_FAST(3, true, true, 1); else FUSED_FAST(3, true, false, 1); }
-        else { if (l0) FUSED_FAST(1, true, true, 2); else FUSED_FAST(1, true, false, 2); }
+        else if (L.outk == 2) { if (l0) FUSED_FAST(1, true, true, 2); else FUSED_FAST(1, true, false, 2); }
+        else { if (l0) FUSED_FAST(1, true, true, 3); else FUSED_FAST(1, true, false, 3); }
     } else if (L.outk == 1) FUSED_FAST(3, false, false, 1);
     else if (L.outk == 2) FUSED_FAST(1, false, false, 2);
+    else if (L.outk == 3) FUSED_FAST(1, false, false, 3);
     else if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
