@@ -1413,6 +1413,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
      * up to six codewords (>= 6, typically >= 32 symbols) from the un-stuffed MEL bits */
     uint64_t msyms = 0; int mcnt = 0; uint32_t mbit = 0; int mel_k = 0;
+    uint32_t pf0 = msrc[0], pf1 = msrc[1], pf2 = msrc[2];   /* the MEL words of the next refill */
 #pragma unroll
     for (int jx = 0; jx < 6; jx++) nx[jx] = make_uint4(0u, 0u, 0u, 0u);
     if (qh > 0) {
@@ -1466,11 +1467,12 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (t) flush((t >> 3) - 1);                  /* behind the loads: nothing waits for these stores for 8 passes */
         }
         if (mcnt < 3) {                                  /* a pair uses at most 3 MEL symbols */
-            const uint32_t *pm = msrc + (mbit >> 5);
             const uint32_t sh = mbit & 31;
-            /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36 */
-            uint64_t mw = ((uint64_t)pm[0] << 32) | pm[1];
-            mw = sh ? ((mw << sh) | ((uint64_t)pm[2] >> (32 - sh))) : mw;
+            /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36.  The three words were
+             * requested at the end of the previous refill (mbit only moves here): with 64 lanes nearly every pass
+             * has some lane refilling, and a fresh load would cost the whole wave a memory round trip each time */
+            uint64_t mw = ((uint64_t)pf0 << 32) | pf1;
+            mw = sh ? ((mw << sh) | ((uint64_t)pf2 >> (32 - sh))) : mw;
 #pragma unroll
             for (int cw = 0; cw < 6; cw++) {
                 const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
@@ -1485,6 +1487,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                     mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
                 }
             }
+            const uint32_t *pm = msrc + (mbit >> 5);
+            pf0 = pm[0]; pf1 = pm[1]; pf2 = pm[2];
         }
         uint64_t vwin;
         {
