@@ -351,7 +351,8 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
             }
             return;
         }
-        if (ib <= ia) return;
+        /* (no early return for lanes without output: the values they hold feed their neighbours' lifting by DPP, and a
+         * divergent region in front of the next step invites the compiler to sink those moves into it) */
         if (TYPE == J2K_DWT97_INT && g.last) {
 #pragma unroll
             for (int c = 0; c < NC; c++)

@@ -45,6 +45,10 @@ struct DevBuf {
         size_t want = n + n / 8 + 256;
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return HTJ2K_ERR_ENOMEM; }
         cap = want;
+        /* test aid: fresh device memory is not zero in a long-lived process; HTJ2K_POISON=1 makes every new buffer
+         * start as 0xA5 bytes so that a read of memory no kernel wrote shows up at once (tools/gpu_random_configs.py) */
+        static const bool poison = getenv("HTJ2K_POISON") && atoi(getenv("HTJ2K_POISON"));
+        if (poison) (void)hipMemset(p, 0xA5, want);
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -408,9 +412,8 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
     for (int f = 0; f < n; f++) {
         FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
-        if (nsamples + pl->nsamples > 0xFFFFFF00ull || nbytes + pl->nbytes > 0xFFFFFF00ull ||
-            j->tilecomps.size() + pl->ntilecomps > 250)      /* J2kBlock.tcomp is a byte */
-            return HTJ2K_ERR_PATCHWELCOME;
+        if (nsamples + pl->nsamples > 0xFFFFFF00ull || nbytes + pl->nbytes > 0xFFFFFF00ull)
+            return HTJ2K_ERR_PATCHWELCOME;                   /* sample and byte offsets of a job are 32-bit */
         F.block_base = (uint32_t)j->blocks.size();
         F.tc_base = (uint32_t)j->tilecomps.size();
         F.sample_base = (uint32_t)nsamples;
@@ -421,7 +424,7 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
             J2kBlock b = pl->blocks[i];
             b.data_off += (uint32_t)nbytes;
             b.plane_off += (uint32_t)nsamples;
-            b.tcomp = (uint8_t)(b.tcomp + F.tc_base);
+            b.tcomp = (uint8_t)(b.tcomp + F.tc_base);          /* informational only (wraps beyond 255 tile-components) */
             j->blocks.push_back(b);
         }
         for (int t = 0; t < pl->ntilecomps; t++) {
@@ -908,6 +911,23 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             F.out.linesize[p] = ls;
             F.out.width[p] = pl->info.plane_width[p];
             F.out.height[p] = pl->info.plane_height[p];
+        }
+        /* Samples of the picture that no tile-component covers (image offsets with subsampling can leave a chroma row
+         * or column out, write_frame_8/16 jpeg2000dec.c:2312-2358) are never written, in the reference either; clear
+         * such planes so that what the caller gets there does not depend on what the buffer held before */
+        for (int p = 0; p < pl->info.nplanes && p < 4; p++) {
+            if (pl->info.has_palette && p == 1) continue;
+            long long covered = 0;
+            int first = -1;                                      /* packed formats: the components share the pixels */
+            for (int t = 0; t < pl->ntilecomps; t++)
+                if (pl->tilecomps[t].out_plane == p && (first < 0 || pl->tilecomps[t].comp < first)) first = pl->tilecomps[t].comp;
+            for (int t = 0; t < pl->ntilecomps; t++) {
+                const J2kTileComp &tc = pl->tilecomps[t];
+                if (tc.out_plane == p && tc.comp == first && tc.out_w > 0 && tc.out_h > 0) covered += (long long)tc.out_w * tc.out_h;
+            }
+            const long long need = (long long)pl->info.plane_width[p] * pl->info.plane_height[p];
+            if (covered < need)
+                HIP_TRY(c, hipMemsetAsync(F.d_out[p].p, 0, (size_t)F.out.linesize[p] * F.out.height[p], j->stream));
         }
     }
     if ((r = build_descriptors(c, j)) < 0) return r;

@@ -46,7 +46,7 @@ typedef struct J2kBlock {
     uint8_t  M_b;        /* expn[subband] + nguardbits - 1 (jpeg2000dec.c:2238) */
     uint8_t  flags;      /* bit 3: J2K_CBLK_VSC; bits 0-1: transform of the component (J2K_DWT*) */
     uint8_t  roi_shift;  /* comp->roi_shift (jpeg2000dec.c:2268) */
-    uint8_t  tcomp;      /* tile-component index (for the status/debug path) */
+    uint8_t  tcomp;      /* tile-component index modulo 256: informational, nothing indexes with it */
     float    f_step;     /* band->f_stepsize (jpeg2000.c:243-264); for 9/7-int: the rounded int scale as float bits unused */
     int32_t  i_step;     /* band->i_stepsize (jpeg2000.c:271); for J2K_DWT97_INT: the (int)(fscale+0.5) scale of jpeg2000dec.c:2164-2168 */
 } J2kBlock;

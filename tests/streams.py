@@ -68,6 +68,15 @@ CASES = {
     "gray_97_offset":    (lambda: _enc((201, 149, 1, 8, 4), nlevels=3, offset=(3, 5), transform=0, qstep=1), {}),
     "gray_97_bitexact":  (lambda: _enc((200, 150, 1, 8, 3), transform=0, qstep=2), {"bitexact": 1}),
     "rgb_97_bitexact":   (lambda: _enc((190, 131, 3, 8, 5), transform=0, mct=1, qstep=1), {"bitexact": 1}),
+    # --- regressions found by tools/gpu_random_configs.py ---
+    # 9/7 fixed point through the general path of the fused final level, last quadruple of a row partly outside the
+    # line (width = 3 mod 4): a lane without output used to leave the lifting of its neighbour short of a DPP source
+    "rgb_97_bitexact_w87": (lambda: _enc((87, 96, 3, 8, 365, 4), transform=0, qstep=4.0, mct=1, nlevels=2, cb=(6, 2)), {"bitexact": 1}),
+    "rgb12_97_bitexact_w91": (lambda: _enc((91, 40, 3, 12, 366, 4), depth=12, transform=0, qstep=4.0, mct=1, nlevels=5, cb=(6, 2)), {"bitexact": 1}),
+    # image offset + 4:2:0: the last chroma row of the picture is covered by no tile-component (jpeg2000dec.c:2312-2358)
+    "yuv420_offset_uncovered_row": (lambda: _enc((377, 15, 3, 8, 169, 4, (1, 2, 2), (1, 2, 2)), nlevels=4, cb=(2, 6), offset=(2, 5), dx=[1, 2, 2], dy=[1, 2, 2], width=377, height=15), {}),
+    # 42 tiles x 3 components = 126 tile-components per frame (a batch of three used to exceed a 250 limit)
+    "yuv420_42_tiles":   (lambda: _enc((212, 168, 3, 8, 337, 4, (1, 2, 2), (1, 2, 2)), nlevels=2, cb=(6, 5), tile=(32, 32), prog=4, dx=[1, 2, 2], dy=[1, 2, 2], width=212, height=168), {}),
     # --- palettised JP2 (pclr + cmap boxes): pal8, the palette is AVFrame.data[1] (jpeg2000dec.c:2900-2901) ---
     "pal8_jp2":           (lambda: vecgen.jp2_wrap(vecgen.encode([(np.add.outer(np.arange(40), np.arange(56)) * 3 % 200).astype(np.int32)], nlevels=2),
                                                    56, 40, 1, 8, colourspace=16,

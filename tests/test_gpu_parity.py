@@ -140,6 +140,31 @@ def test_batch_job_of_mixed_frames(dec, orc, fuse):
         dec.set_int("fuse_pack", 1)
 
 
+def test_batch_of_many_tiles(dec, orc):
+    """a job may hold any number of tile-components (42 tiles x 3 components x 3 frames here)"""
+    data, kw = streams.get("yuv420_42_tiles")
+    info_o, planes_o, _ = orc.decode(data)
+    job = dec.job().parse_batch([data, data, data]).upload().run().wait()
+    assert job.num_tilecomps() == 3 * 126
+    for f in range(3):
+        info, planes = job.download_frame(f)
+        for a, b in zip(planes, planes_o):
+            assert np.array_equal(a, b)
+    job.free()
+
+
+def test_random_configurations(dec, orc):
+    """tools/gpu_random_configs.py as a regression test: 300 random small codestreams (sizes, levels, block shapes,
+    depths, subsampling, 5/3 / 9/7 / 9/7 fixed point, HT / Part-1 / MIXED, tiles, offsets, lowres), each decoded
+    twice in one job, against the oracle"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "gpu_random_configs.py")
+    r = subprocess.run([sys.executable, tool, "300", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "'bad': 0" in r.stdout.splitlines()[-1]
+
+
 def test_pipeline_in_order_with_bad_packets(dec, orc):
     """htj2k_pipe_*: frames come back in send order, bit-identical to the oracle; a packet that does
     not parse costs its own frame only (the rest of its batch is decoded one by one)"""
