@@ -39,6 +39,12 @@ for it in range(N):
     if rng.random() < 0.2: kw["tile"] = (int(rng.choice([32, 64, 96, 100])), int(rng.choice([32, 48, 64, 70])))
     if rng.random() < 0.15: kw["offset"] = (int(rng.integers(0, 9)), int(rng.integers(0, 9)))
     if rng.random() < 0.2: kw["prog"] = int(rng.integers(0, 5))
+    if rng.random() < 0.15: kw["prec"] = [(int(rng.integers(5, 9)), int(rng.integers(5, 9))), (int(rng.integers(4, 8)), int(rng.integers(4, 8)))]
+    if rng.random() < 0.1: kw.update(sop=True, eph=bool(rng.integers(0, 2)))
+    if rng.random() < 0.1 and not kw.get("part1") and not kw.get("mixed"): kw["placeholder_sets"] = int(rng.integers(1, 3))
+    if rng.random() < 0.1: kw["guard_bits"] = int(rng.integers(1, 5))
+    if rng.random() < 0.1 and kw.get("part1"): kw["drop_passes"] = int(rng.integers(1, 6))
+    if rng.random() < 0.05: kw["force_include"] = True
     opts = {}
     if rng.random() < 0.1 and nl > 0: opts["reduction_factor"] = int(rng.integers(1, nl + 1))
     if kw.get("transform") == 0 and rng.random() < 0.3: opts["bitexact"] = 1
