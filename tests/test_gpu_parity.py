@@ -160,9 +160,10 @@ def test_random_configurations(dec, orc):
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(HERE), "tools", "gpu_random_configs.py")
-    r = subprocess.run([sys.executable, tool, "300", "5"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "'bad': 0" in r.stdout.splitlines()[-1]
+    for env, seed in ({}, "5"), ({"C16BIAS": "1"}, "6"):           # the second draw: mostly jobs that take the 16-bit sub-band path
+        r = subprocess.run([sys.executable, tool, "300", seed], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "'bad': 0" in r.stdout.splitlines()[-1]
 
 
 def test_pipeline_in_order_with_bad_packets(dec, orc):

@@ -17,6 +17,7 @@ stat = dict(ok=0, c16=0, enc_fail=0, frame_err=0, bad=0)
 ONLY = set(int(v) for v in os.environ["ONLY"].split(",")) if os.environ.get("ONLY") else None
 t0 = time.time()
 for it in range(N):
+    c16bias = os.environ.get("C16BIAS") == "1"         # mostly jobs that qualify for 16-bit sub-bands and the fast stores
     even = rng.random() < 0.6
     w = int(rng.integers(1, 12)) * 32 if even else int(rng.integers(1, 400))
     h = int(rng.integers(1, 10)) * 16 if even else int(rng.integers(1, 300))
@@ -36,7 +37,21 @@ for it in range(N):
     dy = [1, int(rng.choice([1, 2])), 0] if sub else None
     if sub: dy[2] = dy[1]
     if nc >= 3 and not sub and rng.random() < 0.6: kw["mct"] = 1
-    if rng.random() < 0.2: kw["tile"] = (int(rng.choice([32, 64, 96, 100])), int(rng.choice([32, 48, 64, 70])))
+    if c16bias and rng.random() < 0.85:
+        nl = int(rng.integers(1, 5))
+        w = int(rng.integers(1, 9)) * (8 << nl)
+        h = int(rng.integers(2, 200))
+        nc = int(rng.choice([1, 3, 3]))
+        depth = int(rng.choice([8, 8, 10]))
+        cbw = int(rng.integers(2, 7)); cbh = int(rng.integers(2, min(10, 12 - cbw) + 1))
+        kw = dict(nlevels=nl, cb=(cbw, cbh), depth=depth)
+        sub = nc == 3 and rng.random() < 0.3
+        dx = [1, 2, 2] if sub else None
+        dy = [1, 1, 1] if sub else None
+        if sub and (w // 2) % (8 << nl): sub, dx, dy = False, None, None
+        if nc == 3 and not sub and rng.random() < 0.7: kw["mct"] = 1
+        if rng.random() < 0.3: kw["tile"] = (int(rng.integers(1, 4)) * (8 << nl), int(rng.choice([32, 64, 96, 128])))
+    if rng.random() < 0.2 and "tile" not in kw: kw["tile"] = (int(rng.choice([32, 64, 96, 100])), int(rng.choice([32, 48, 64, 70])))
     if rng.random() < 0.15: kw["offset"] = (int(rng.integers(0, 9)), int(rng.integers(0, 9)))
     if rng.random() < 0.2: kw["prog"] = int(rng.integers(0, 5))
     if rng.random() < 0.15: kw["prec"] = [(int(rng.integers(5, 9)), int(rng.integers(5, 9))), (int(rng.integers(4, 8)), int(rng.integers(4, 8)))]
