@@ -69,6 +69,15 @@ for it in range(N):
         img = vecgen.synth_image(w, h, nc, depth=depth, seed=it + 7, noise=int(rng.choice([0, 4, 20])), dx=dx, dy=dy)
         if sub: kw.update(dx=dx, dy=dy, width=w, height=h)
         data = vecgen.encode(img, **kw)
+        # now and then inside a JP2 file: enumerated colourspace (16 sRGB, 17 grey, 18 sYCC -> planar YUV) and, for
+        # three components, a channel definition box that permutes them (write_frame's plane choice, jpeg2000dec.c:2326)
+        if rng.random() < 0.15 and nc in (1, 3):
+            cs = 17 if nc == 1 else int(rng.choice([16, 18]))
+            cdef = None
+            if nc == 3 and rng.random() < 0.5:
+                perm = rng.permutation(3)
+                cdef = [(c, 0, int(perm[c]) + 1) for c in range(3)]
+            data = vecgen.jp2_wrap(data, w, h, nc, depth, colourspace=cs, cdef=cdef)
     except Exception as e:
         stat["enc_fail"] += 1
         continue
