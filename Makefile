@@ -37,7 +37,10 @@ $(CSRC)/htj2k_pipe.o: $(CSRC)/htj2k_pipe.cpp include/htj2k_amd.h
 $(CSRC)/j2k_split.o: $(CSRC)/j2k_split.c include/htj2k_amd.h
 	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
 
-$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o $(CSRC)/j2k_split.o
+$(CSRC)/j2k_mxf.o: $(CSRC)/j2k_mxf.c include/htj2k_amd.h
+	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
+
+$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o $(CSRC)/j2k_split.o $(CSRC)/j2k_mxf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 # The oracle links the same host parser object as the product (parsing is not on the

@@ -7,6 +7,8 @@
  *                                            (htj2k_pipe_*), frames written are those of the last round
  *   htj2k_decode -s in.j2k [out.raw]         a sequence of back-to-back codestreams / JP2 files: cut into packets by
  *                                            htj2k_splitter_* (64 KB reads), every frame decoded and written
+ *   htj2k_decode -x in.mxf [out.raw]         the frame-wrapped JPEG 2000 picture elements of an MXF file
+ *                                            (htj2k_mxf_next_essence; first picture track), decoded and written
  *
  * build: make examples   (cc examples/htj2k_decode.c -Iinclude -Lffmpeg-ht_amd -lhtj2k_amd)
  */
@@ -88,12 +90,59 @@ static int decode_sequence(const char *in, const char *outname)
     return 0;
 }
 
+/* -x: what the reference's mxf demuxer hands to the decoder packet by packet (libavformat/mxfdec.c:4034-4160) */
+static int decode_mxf(const char *in, const char *outname)
+{
+    FILE *f = fopen(in, "rb"), *o = outname ? fopen(outname, "wb") : NULL;
+    if (!f || (outname && !o)) { perror(f ? outname : in); return 2; }
+    fseek(f, 0, SEEK_END);
+    long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *file = calloc(1, (size_t)size + 64), *pkt = NULL;
+    if (!file || fread(file, 1, (size_t)size, f) != (size_t)size) { fprintf(stderr, "read failed\n"); return 2; }
+    fclose(f);
+    htj2k_opts opts;
+    memset(&opts, 0, sizeof(opts));
+    opts.req_pix_fmt = HTJ2K_PIX_NONE;
+    htj2k_ctx *ctx = NULL;
+    int r = htj2k_open(&opts, &ctx), nframes = 0;
+    if (r < 0) { fprintf(stderr, "htj2k_open: %d\n", r); return 1; }
+    htj2k_set_log(ctx, log_cb, NULL);
+    size_t pos = 0;
+    uint32_t track = 0;
+    htj2k_mxf_essence es;
+    while ((r = htj2k_mxf_next_essence(file, (size_t)size, &pos, &es)) == 1) {
+        if (es.wrapping != HTJ2K_MXF_FRAME_WRAPPED) { fprintf(stderr, "clip-wrapped essence: use -s on the element\n"); continue; }
+        if (!track) track = es.track_number;
+        if (es.track_number != track) continue;              /* one picture track */
+        htj2k_info info;
+        htj2k_frame fr;
+        pkt = realloc(pkt, es.size + 64);                    /* the packet with its input padding, as av_get_packet() */
+        if (!pkt) return 1;
+        memcpy(pkt, es.data, es.size);
+        memset(pkt + es.size, 0, 64);
+        if ((r = htj2k_probe(ctx, pkt, (int)es.size, &info)) < 0 || alloc_planes(&info, &fr) < 0 ||
+            (r = htj2k_decode(ctx, pkt, (int)es.size, &fr, NULL)) < 0) { fprintf(stderr, "frame %d: %d\n", nframes, r); return 1; }
+        for (int p = 0; o && p < info.nplanes; p++)
+            fwrite(fr.data[p], 1, (size_t)fr.linesize[p] * info.plane_height[p], o);
+        for (int p = 0; p < 4; p++) free(fr.data[p]);
+        printf("frame %d: %zu bytes at %zu, %dx%d pix_fmt %d\n", nframes++, es.size, es.klv_offset, info.width, info.height, info.pix_fmt);
+    }
+    if (r < 0) { fprintf(stderr, "htj2k_mxf_next_essence: %d\n", r); return 1; }
+    if (o) fclose(o);
+    free(pkt);
+    free(file);
+    htj2k_close(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int npipe = 0, a = 1;
+    if (argc > 2 && !strcmp(argv[1], "-x")) return decode_mxf(argv[2], argc > 3 ? argv[3] : NULL);
     if (argc > 2 && !strcmp(argv[1], "-s")) return decode_sequence(argv[2], argc > 3 ? argv[3] : NULL);
     if (argc > 2 && !strcmp(argv[1], "-p")) { npipe = atoi(argv[2]); a = 3; }
-    if (argc <= a) { fprintf(stderr, "usage: %s [-p N | -s] in.j2c [out.raw]\n", argv[0]); return 2; }
+    if (argc <= a) { fprintf(stderr, "usage: %s [-p N | -s | -x] in.j2c [out.raw]\n", argv[0]); return 2; }
     FILE *f = fopen(argv[a], "rb");
     if (!f) { perror(argv[a]); return 2; }
     fseek(f, 0, SEEK_END);

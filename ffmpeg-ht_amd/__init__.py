@@ -80,7 +80,8 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
            "htj2k_pipe_receive_device", "htj2k_job_device_frame",
-           "htj2k_splitter_open", "htj2k_splitter_find_end", "htj2k_splitter_parse", "htj2k_splitter_close"]
+           "htj2k_splitter_open", "htj2k_splitter_find_end", "htj2k_splitter_parse", "htj2k_splitter_close",
+           "htj2k_mxf_next_essence"]
 
 _lib = None
 
@@ -302,6 +303,27 @@ class Splitter:
             self.close()
         except Exception:
             pass
+
+
+class MxfEssence(ctypes.Structure):
+    """struct htj2k_mxf_essence (include/htj2k_amd.h)"""
+    _fields_ = [("data", ctypes.POINTER(ctypes.c_uint8)), ("size", ctypes.c_size_t), ("klv_offset", ctypes.c_size_t),
+                ("track_number", ctypes.c_uint32), ("wrapping", ctypes.c_int)]
+
+
+MXF_FRAME_WRAPPED, MXF_CLIP_WRAPPED = 1, 2
+
+
+def mxf_essence(data):
+    """htj2k_mxf_next_essence over a whole MXF file: [(bytes, track_number, wrapping, klv_offset)] of its JPEG 2000
+    picture elements (the KLV layer of libavformat/mxfdec.c).  Host only: works without a GPU."""
+    L = load_library()
+    L.htj2k_mxf_next_essence.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(MxfEssence)]
+    data = bytes(data)
+    pos, e, out = ctypes.c_size_t(0), MxfEssence(), []
+    while _check(L.htj2k_mxf_next_essence(data, len(data), ctypes.byref(pos), ctypes.byref(e)), "htj2k_mxf_next_essence") == 1:
+        out.append((ctypes.string_at(e.data, e.size), e.track_number, e.wrapping, e.klv_offset))
+    return out
 
 
 class Pipe:

@@ -273,6 +273,25 @@ int  htj2k_splitter_find_end(htj2k_splitter *sp, const uint8_t *buf, int size);
 int  htj2k_splitter_parse(htj2k_splitter *sp, const uint8_t *buf, int size, const uint8_t **frame, int *frame_size);
 void htj2k_splitter_close(htj2k_splitter *sp);
 
+/* ---- MXF: JPEG 2000 picture essence out of a file held in memory ------------------------------------
+ * The KLV layer of the reference's demuxer (klv_read_packet, libavformat/mxfdec.c:432-504, and the essence
+ * branch of mxf_read_packet, :4034-4160); no header metadata is read.  Starting at *pos, finds the next
+ * generic-container picture element that carries JPEG 2000 (SMPTE 422M: key ...0d.01.03.01.15.nn.08.nn
+ * frame-wrapped, ...15.nn.09.nn clip-wrapped; libavformat/mxfenc.c:216-217) and advances *pos behind it.
+ * Returns 1 with *out filled in (pointing into `buf`), 0 at the end of the buffer, < 0 on a malformed length.
+ * A frame-wrapped element is one packet for htj2k_decode / htj2k_pipe_send; a clip-wrapped one holds all
+ * codestreams back to back and is cut apart by htj2k_splitter_*. */
+#define HTJ2K_MXF_FRAME_WRAPPED 1
+#define HTJ2K_MXF_CLIP_WRAPPED  2
+typedef struct htj2k_mxf_essence {
+    const uint8_t *data;
+    size_t   size;                /* shorter than the KLV length when the file is truncated */
+    size_t   klv_offset;          /* of the element's key (AVPacket.pos) */
+    uint32_t track_number;        /* key bytes 12..15: matches the track's TrackNumber (SMPTE 379M 7.3) */
+    int      wrapping;
+} htj2k_mxf_essence;
+int  htj2k_mxf_next_essence(const uint8_t *buf, size_t size, size_t *pos, htj2k_mxf_essence *out);
+
 const char *htj2k_version(void);
 /* name of the device the context is bound to, e.g. "gfx950" */
 const char *htj2k_device_name(htj2k_ctx *ctx);

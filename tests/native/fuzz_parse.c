@@ -1,5 +1,6 @@
 /* fuzz_parse.c -- test harness (built with -fsanitize=address,undefined by tests/test_parser_fuzz.py): mutated
- * codestreams through the host parser j2k_parse() and the frame splitter htj2k_splitter_*.  Every packet is copied into an exact-size heap buffer, so an
+ * codestreams through the host parser j2k_parse(), the frame splitter htj2k_splitter_* and the MXF essence walker
+ * htj2k_mxf_next_essence.  Every packet is copied into an exact-size heap buffer, so an
  * over-read of the packet is an ASan report; every accepted plan is checked the way the device layer would walk it
  * (block bytes inside the byte pool, block windows inside the coefficient planes).
  * usage: fuzz_parse ITERATIONS file... */
@@ -43,6 +44,21 @@ int main(int argc,char**argv){
           free(q); pos+=k; }
         { const uint8_t*fr=NULL; int fs=0; htj2k_splitter_parse(sp,NULL,0,&fr,&fs); if(fr&&fs>0){ volatile uint8_t t1=fr[fs-1]; (void)t1; } }
         htj2k_splitter_close(sp); (void)frames; }
+      /* the same bytes behind an MXF essence key with a random BER length form, header bytes mutated, through the
+       * KLV walker: every element handed out must lie inside the (exact-size) buffer */
+      { static const uint8_t key[16]={0x06,0x0e,0x2b,0x34,0x01,0x02,0x01,0x01,0x0d,0x01,0x03,0x01,0x15,0x01,0x08,0x01};
+        int nb=1+rnd()%8; long tot=3+16+1+nb+m+(rnd()%3?16:0); uint8_t*q=malloc(tot); long w=0;
+        q[w++]=0x06;q[w++]=0x0e;q[w++]=0x2b; memcpy(q+w,key,16); w+=16; q[w++]=0x80|nb;
+        for(int t=nb-1;t>=0;t--) q[w++]= t<8 ? (uint8_t)((uint64_t)m>>(8*t)) : 0;
+        memcpy(q+w,c,m); w+=m; while(w<tot){ q[w]=key[w&15]; w++; }
+        if(rnd()%2){ int k=1+rnd()%3; for(int i=0;i<k;i++) q[rnd()%(20+nb)]=rnd(); }
+        if(rnd()%4==0) tot=rnd()%(tot+1);
+        { uint8_t*e=malloc(tot+1); memcpy(e,q,tot); size_t pos=0; htj2k_mxf_essence es; int r2, guard=0;
+          while((r2=htj2k_mxf_next_essence(e,(size_t)tot,&pos,&es))==1 && guard++<1000){
+            if(es.data<e||es.data+es.size>e+tot||pos>(size_t)tot){printf("MXF element outside the buffer\n");abort();}
+            if(es.size){ volatile uint8_t t0=es.data[0],t1=es.data[es.size-1]; (void)t0;(void)t1; } }
+          free(e); }
+        free(q); }
       free(c);
     }
     free(b);

@@ -682,3 +682,12 @@ def test_c_example_program(orc, tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.count("frame ") == len(names), r.stdout
     assert out.read_bytes() == want
+    # -x: the same frames as frame-wrapped picture elements of an MXF file, beside sound elements and fill
+    import test_mxf
+    mxf = tmp_path / "sequence.mxf"
+    mxf.write_bytes(test_mxf._mxf([streams.get(n)[0] for n in names], run_in=b"\x00" * 37))
+    out = tmp_path / "mxf.raw"
+    r = subprocess.run([exe, "-x", str(mxf), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.count("frame ") == len(names), r.stdout
+    assert out.read_bytes() == want
