@@ -987,35 +987,42 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
  * pass.  A byte whose 7 LSBs are set loses its MSB when the byte read before it is > 0x8F
  * (jpeg2000htdec.c:145-201); the byte "before" the first one is 0xFF.  `first_or` is ORed into the first
  * byte (the VLC stream's Dcup[Lcup-2] counts with its low nibble set, :1277-1278).  `out` (LDS) is zeroed. */
+__device__ __forceinline__ void ht_unstuff_backward_step(uint32_t dw, uint32_t k0, uint32_t n, uint32_t first_or,
+                                                         uint32_t *out, int lane, uint32_t &base, uint32_t &carry)
+{
+    const uint32_t k = k0 + 4 * lane;                    /* read index of r0; dw = the four bytes top[-k-3 .. -k] */
+    const int nv = min(max((int)n - (int)k, 0), 4);
+    uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
+    if (k == 0) r0 |= first_or;
+    if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
+    uint32_t above = ht_dpp_left(r3);
+    if (lane == 0) above = carry;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
+    const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+    const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+    const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+    const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+    const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+    const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
+                           ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
+    const uint32_t incl = wave_incl_scan_u32(tot, lane);
+    const uint32_t off = base + incl - tot, sh = off & 31;
+    if (nv > 0) {
+        atomicOr(&out[off >> 5], chunk << sh);
+        if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
+    }
+    base += wave_last(incl);
+}
+
 __device__ __forceinline__ uint32_t ht_unstuff_backward(const uint8_t *__restrict__ top, uint32_t n, uint32_t first_or,
                                                         uint32_t *out, int lane)
 {
     uint32_t base = 0, carry = 0xFF;
     for (uint32_t k0 = 0; k0 < n; k0 += 256) {
-        const uint32_t k = k0 + 4 * lane;                /* read index of r0 */
-        const int nv = min(max((int)n - (int)k, 0), 4);
+        const uint32_t k = k0 + 4 * lane;
         uint32_t dw = 0;
-        if (nv > 0) __builtin_memcpy(&dw, top - k - 3, 4);     /* up to 3 bytes in front of the stream: block bytes or pad */
-        uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
-        if (k == 0) r0 |= first_or;
-        if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
-        uint32_t above = ht_dpp_left(r3);
-        if (lane == 0) above = carry;
-        carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
-        const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-        const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-        const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-        const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
-        const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
-                               ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
-        const uint32_t incl = wave_incl_scan_u32(tot, lane);
-        const uint32_t off = base + incl - tot, sh = off & 31;
-        if (nv > 0) {
-            atomicOr(&out[off >> 5], chunk << sh);
-            if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
-        }
-        base += wave_last(incl);
+        if (k < n) __builtin_memcpy(&dw, top - k - 3, 4);      /* up to 3 bytes in front of the stream: block bytes or pad */
+        ht_unstuff_backward_step(dw, k0, n, first_or, out, lane, base, carry);
     }
     return base;
 }
@@ -1069,11 +1076,30 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     if (b.npasses == 0 || b.lcup < 2) return;
     const uint8_t *D = bytes + b.data_off;
     const uint32_t Lcup = b.lcup;
-    const uint32_t Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+    /* A wave lives as long as its chain of dependent global loads.  The first 1024 bytes of the VLC stream (read
+     * backward from Dcup[Lcup-2]) are fetched before Scup -- which says how many of them count -- is known: the
+     * addresses depend on Lcup only and stay inside the byte pool (blocks in front, 16 bytes of pad at its start). */
+    uint32_t pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const long long o = (long long)b.data_off + Lcup - 5 - (256 * j + 4 * lane);
+        pv[j] = 0;
+        if (o >= 0) __builtin_memcpy(&pv[j], bytes + o, 4);
+    }
+    const uint32_t Scup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F)));
     if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
     const uint32_t Pcup = Lcup - Scup;
     const uint32_t nsw = ht_nsw(Scup);
     if (2 * nsw > lds_words) return;                     /* host sized the LDS from the same fields */
+    /* ... and the first 1024 bytes of the MEL stream (forward from Dcup[Pcup]) are in flight while the VLC bytes
+     * are worked on; the block's trailing pad bytes cover the tail */
+    uint32_t pm[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = 256 * j + 4 * lane;
+        pm[j] = 0;
+        if (i < Scup) __builtin_memcpy(&pm[j], D + Pcup + i, 4);
+    }
     uint32_t *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
     uint32_t *sv = sw, *sm = sw + nsw;
 
@@ -1081,18 +1107,29 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     __syncthreads();
 
     /* ---- VLC: backward from Dcup[Lcup-2] ---- */
-    ht_unstuff_backward(D + Lcup - 2, Scup - 1, 0x0F, sv, lane);
+    {
+        const uint8_t *top = D + Lcup - 2;
+        const uint32_t n = Scup - 1;
+        uint32_t base = 0, carry = 0xFF;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (256u * j < n) ht_unstuff_backward_step(pv[j], 256 * j, n, 0x0F, sv, lane, base, carry);
+        for (uint32_t k0 = 1024; k0 < n; k0 += 256) {
+            const uint32_t k = k0 + 4 * lane;
+            uint32_t dw = 0;
+            if (k < n) __builtin_memcpy(&dw, top - k - 3, 4);
+            ht_unstuff_backward_step(dw, k0, n, 0x0F, sv, lane, base, carry);
+        }
+    }
 
     /* ---- MEL: forward from Dcup[Pcup], MSB-first; Dcup[Lcup-1] counts as 0xFF, Dcup[Lcup-2] with
      * its low nibble set; a byte after 0xFF has 7 bits (:429-440) ---- */
     uint32_t mel_bits = 0;
     {
         uint32_t base = 0, carry = 0;
-        for (uint32_t i0 = 0; i0 < Scup; i0 += 256) {
+        auto mel_step = [&](uint32_t dw, uint32_t i0) {
             const uint32_t i = i0 + 4 * lane;
             const int nv = min(max((int)Scup - (int)i, 0), 4);
-            uint32_t dw = 0;
-            if (nv > 0) __builtin_memcpy(&dw, D + Pcup + i, 4);      /* the block's trailing pad bytes cover the tail */
             uint32_t m[4] = { dw & 0xFF, (dw >> 8) & 0xFF, (dw >> 16) & 0xFF, dw >> 24 };
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -1122,6 +1159,15 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
                 if (sh) atomicOr(&sm[(off >> 5) + 1], left << (32 - sh));
             }
             base += wave_last(incl);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (256u * j < Scup) mel_step(pm[j], 256 * j);
+        for (uint32_t i0 = 1024; i0 < Scup; i0 += 256) {
+            const uint32_t i = i0 + 4 * lane;
+            uint32_t dw = 0;
+            if (i < Scup) __builtin_memcpy(&dw, D + Pcup + i, 4);
+            mel_step(dw, i0);
         }
         mel_bits = base;
     }
