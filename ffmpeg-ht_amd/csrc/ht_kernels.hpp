@@ -7,7 +7,7 @@
  * (jpeg2000dec.c:2279-2287).  How it computes it is not the reference's byte-at-a-time
  * bit buffers.  The work of a block splits by its dependence structure:
  *
- *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, MEL, SigProp, MagRef bytes) and the
+ *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, SigProp, MagRef bytes) and the
  *                       head of k_ht_decode (MagSgn): four bytes per lane, per-byte bit counts
  *                       (7 after a 0xFF, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
  *                       >0x8F byte for the backward streams, :145-201), wave prefix sum -> bit
@@ -969,12 +969,12 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
 
 
 /* ================================================================== split pipeline
- * k_ht_unstuff  (wave per block)  removes the bit stuffing of the VLC and MEL byte streams of the
- *               cleanup segment in parallel (four bytes per lane: per-byte bit counts, wave
- *               prefix sum, ds_or) and writes them as plain bit arrays: VLC LSB-first in read
- *               order padded with zeros (jpeg2000htdec.c:145-201, first 4 bits = the Scup
- *               nibble), MEL MSB-first padded with ones (:429-440).  (MagSgn is un-stuffed by
- *               k_ht_decode itself, straight into LDS.)
+ * k_ht_unstuff  (wave per block)  removes the bit stuffing of the VLC byte stream of the cleanup
+ *               segment in parallel (four bytes per lane: per-byte bit counts, wave prefix sum,
+ *               ds_or) and writes it as a plain bit array: LSB-first in read order padded with
+ *               zeros (jpeg2000htdec.c:145-201, first 4 bits = the Scup nibble).  (MagSgn is
+ *               un-stuffed by k_ht_decode itself, straight into LDS; the MEL stream -- short,
+ *               but of unknown length -- is read from the raw bytes by k_ht_vlc, :429-440.)
  * k_ht_vlc      (LANE per block)  the serial MEL / CxtVLC / U-VLC chain (:632-973); 64 blocks
  *               per wavefront.  With stuffing gone a refill is "append the next dword", a MEL
  *               read is a shift, and the first-row / other-row / paired / unpaired U-VLC cases
@@ -1088,22 +1088,12 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     }
     const uint32_t Scup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F)));
     if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
-    const uint32_t Pcup = Lcup - Scup;
     const uint32_t nsw = ht_nsw(Scup);
     if (2 * nsw > lds_words) return;                     /* host sized the LDS from the same fields */
-    /* ... and the first 1024 bytes of the MEL stream (forward from Dcup[Pcup]) are in flight while the VLC bytes
-     * are worked on; the block's trailing pad bytes cover the tail */
-    uint32_t pm[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = 256 * j + 4 * lane;
-        pm[j] = 0;
-        if (i < Scup) __builtin_memcpy(&pm[j], D + Pcup + i, 4);
-    }
     uint32_t *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
-    uint32_t *sv = sw, *sm = sw + nsw;
+    uint32_t *sv = sw;
 
-    for (uint32_t i = lane; i < 2 * nsw; i += 64) sw[i] = 0;
+    for (uint32_t i = lane; i < nsw; i += 64) sw[i] = 0;
     __syncthreads();
 
     /* ---- VLC: backward from Dcup[Lcup-2] ---- */
@@ -1122,63 +1112,11 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
         }
     }
 
-    /* ---- MEL: forward from Dcup[Pcup], MSB-first; Dcup[Lcup-1] counts as 0xFF, Dcup[Lcup-2] with
-     * its low nibble set; a byte after 0xFF has 7 bits (:429-440) ---- */
-    uint32_t mel_bits = 0;
-    {
-        uint32_t base = 0, carry = 0;
-        auto mel_step = [&](uint32_t dw, uint32_t i0) {
-            const uint32_t i = i0 + 4 * lane;
-            const int nv = min(max((int)Scup - (int)i, 0), 4);
-            uint32_t m[4] = { dw & 0xFF, (dw >> 8) & 0xFF, (dw >> 16) & 0xFF, dw >> 24 };
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t a = Pcup + i + q;
-                if (a == Lcup - 1) m[q] = 0xFF;
-                else if (a == Lcup - 2) m[q] |= 0x0F;
-                if (q >= nv) m[q] = 0;
-            }
-            uint32_t prev = ht_dpp_left(m[3]);
-            if (lane == 0) prev = carry;
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)m[3], 63);
-            const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
-            const uint32_t n1 = nv > 1 ? (m[0] == 0xFF ? 7u : 8u) : 0u;
-            const uint32_t n2 = nv > 2 ? (m[1] == 0xFF ? 7u : 8u) : 0u;
-            const uint32_t n3 = nv > 3 ? (m[2] == 0xFF ? 7u : 8u) : 0u;
-            const uint32_t tot = n0 + n1 + n2 + n3;
-            /* first byte in the most significant bits */
-            uint32_t chunk = m[0] & ((1u << n0) - 1);
-            chunk = (chunk << n1) | (m[1] & ((1u << n1) - 1));
-            chunk = (chunk << n2) | (m[2] & ((1u << n2) - 1));
-            chunk = (chunk << n3) | (m[3] & ((1u << n3) - 1));
-            const uint32_t incl = wave_incl_scan_u32(tot, lane);
-            const uint32_t off = base + incl - tot, sh = off & 31;
-            if (nv > 0) {
-                const uint32_t left = chunk << (32 - tot);            /* tot is 7..32 here */
-                atomicOr(&sm[off >> 5], left >> sh);
-                if (sh) atomicOr(&sm[(off >> 5) + 1], left << (32 - sh));
-            }
-            base += wave_last(incl);
-        };
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (256u * j < Scup) mel_step(pm[j], 256 * j);
-        for (uint32_t i0 = 1024; i0 < Scup; i0 += 256) {
-            const uint32_t i = i0 + 4 * lane;
-            uint32_t dw = 0;
-            if (i < Scup) __builtin_memcpy(&dw, D + Pcup + i, 4);
-            mel_step(dw, i0);
-        }
-        mel_bits = base;
-    }
+    /* (the MEL stream, forward from Dcup[Pcup], is read from the raw bytes by k_ht_vlc: it is a few dozen bytes
+     * in most blocks, but where it ends is not signalled, and un-stuffing all Scup bytes for it was half of this
+     * kernel's work) */
     __syncthreads();
-    for (uint32_t i = lane; i < nsw; i += 64) {
-        vlO[i] = sv[i];
-        uint32_t v = sm[i];                               /* 0xFF bytes forever past the segment */
-        if (i * 32 >= mel_bits) v = 0xFFFFFFFFu;
-        else if (i * 32 + 32 > mel_bits) v |= 0xFFFFFFFFu >> (mel_bits & 31);
-        meO[i] = v;
-    }
+    for (uint32_t i = lane; i < nsw; i += 64) vlO[i] = sv[i];
 
     /* ---- refinement segment (blocks with more than the cleanup pass): SigProp forward, MagRef backward
      * over Dref = Dcup + Lcup (:1016-1185, :1260); zero bits past either end ---- */
@@ -1418,12 +1356,15 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     int qw = 0, qh = 0;
     uint32_t doff = 0;
     uint32_t *qout = qsym;
+    const uint8_t *mraw = bytes + 16;                    /* Dcup + Pcup: the MEL bytes; lanes without a block read the pool's front pad */
+    int mlim = 0;                                        /* Scup */
     if (bi < nblocks) {
         const J2kBlock b = blocks[bi];
         bool ok = b.npasses != 0 && b.lcup >= 2;
+        uint32_t Scup = 0;
         if (ok) {
             const uint8_t *D = bytes + b.data_off;
-            const uint32_t Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
+            Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
             ok = !(Scup < 2 || Scup > b.lcup || Scup > 4079);
         }
         if (ok && ((b.w + 1u) >> 1) <= max_qw) {
@@ -1431,6 +1372,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             qh = (b.h + 1) >> 1;
             qout = qsym + qoff[bi];
             doff = b.data_off >> 2;
+            mraw = bytes + b.data_off + (b.lcup - Scup);
+            mlim = (int)Scup;
         }
     }
     /* one flat loop, the same number of passes for every lane of the wave: lane-local (row, qx)
@@ -1448,7 +1391,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     }
     __syncthreads();
 
-    const uint32_t *vsrc = vlc_u + doff, *msrc = mel_u + doff;
+    const uint32_t *vsrc = vlc_u + doff;
     uint8_t *myrho = rho_rows + lane * pitch;
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
     uint32_t *vst = vstage + lane * HT_VSTAGE_PITCH;
@@ -1457,9 +1400,15 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint32_t sbase = 0, nbase = 0;                       /* word index of vst[0] / of nx[0] */
     /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
-     * up to six codewords (>= 6, typically >= 32 symbols) from the un-stuffed MEL bits */
-    uint64_t msyms = 0; int mcnt = 0; uint32_t mbit = 0; int mel_k = 0;
-    uint32_t pf0 = msrc[0], pf1 = msrc[1], pf2 = msrc[2];   /* the MEL words of the next refill */
+     * up to six codewords (>= 6, typically >= 32 symbols).  The stream is read from the raw bytes Dcup[Pcup ...]
+     * (:429-440: MSB first, a byte behind 0xFF has 7 bits, Dcup[Lcup-1] counts as 0xFF and Dcup[Lcup-2] with its low
+     * nibble set, 0xFF for ever behind the segment).  `mrb` is the position in raw bits: bit 0 of a byte behind 0xFF
+     * is never pointed at. */
+    uint64_t msyms = 0; int mcnt = 0; uint32_t mrb = 0; int mel_k = 0;
+    uint32_t pfA, pfB, pfC;                              /* raw bytes -1 .. 10 around the next refill's position */
+    __builtin_memcpy(&pfA, mraw - 1, 4);
+    __builtin_memcpy(&pfB, mraw + 3, 4);
+    __builtin_memcpy(&pfC, mraw + 7, 4);
 #pragma unroll
     for (int jx = 0; jx < 6; jx++) nx[jx] = make_uint4(0u, 0u, 0u, 0u);
     if (qh > 0) {
@@ -1513,12 +1462,38 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (t) flush((t >> 3) - 1);                  /* behind the loads: nothing waits for these stores for 8 passes */
         }
         if (mcnt < 3) {                                  /* a pair uses at most 3 MEL symbols */
-            const uint32_t sh = mbit & 31;
-            /* 64 MEL bits from mbit, first bit in the MSB; six codewords need <= 36.  The three words were
-             * requested at the end of the previous refill (mbit only moves here): with 64 lanes nearly every pass
+            /* >= 42 MEL bits from mrb, first bit in the MSB; six codewords need <= 36.  The twelve bytes were
+             * requested at the end of the previous refill (mrb only moves here): with 64 lanes nearly every pass
              * has some lane refilling, and a fresh load would cost the whole wave a memory round trip each time */
-            uint64_t mw = ((uint64_t)pf0 << 32) | pf1;
-            mw = sh ? ((mw << sh) | ((uint64_t)pf2 >> (32 - sh))) : mw;
+            const int mb = (int)(mrb >> 3);
+            const uint32_t o = mrb & 7;
+            const uint32_t a0 = mb ? pfA : (pfA & ~0xFFu);              /* the first byte of the stream has 8 bits */
+            const uint32_t anyff = ((~a0 - 0x01010101u) & a0 & 0x80808080u) | ((~pfB - 0x01010101u) & pfB & 0x80808080u);
+            const bool slow = anyff != 0 || mb + 10 > mlim;             /* a 0xFF in bytes -1 .. 6, or the segment's end near */
+            uint64_t mw;
+            uint32_t n7 = 0;                                            /* bit j: byte j of the window has 7 bits */
+            if (!slow) {
+                const uint32_t hi = __builtin_amdgcn_perm(pfB, pfA, 0x01020304u), lo = __builtin_amdgcn_perm(pfC, pfB, 0x01020304u);
+                mw = (((uint64_t)hi << 32) | lo) << o;
+            } else {
+                uint32_t prev = 0, total = 0;
+                mw = 0;
+#pragma unroll
+                for (int j = -1; j < 7; j++) {
+                    const int p = mb + j;
+                    const uint32_t raw = ((j < 3 ? pfA >> (8 * (j + 1)) : pfB >> (8 * (j - 3)))) & 0xFF;
+                    const uint32_t v = p >= mlim - 1 ? 0xFFu : (p == mlim - 2 ? raw | 0x0Fu : raw);
+                    if (j >= 0) {
+                        const uint32_t n = prev == 0xFF ? 7u : 8u;
+                        mw = (mw << n) | (v & ((1u << n) - 1));
+                        total += n;
+                        n7 |= (8u - n) << j;
+                    }
+                    prev = p < 0 ? 0u : v;
+                }
+                mw <<= (64 - total) + (o - (n7 & 1));
+            }
+            uint32_t used_all = 0;
 #pragma unroll
             for (int cw = 0; cw < 6; cw++) {
                 const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
@@ -1529,12 +1504,28 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                     if (!b) msyms |= 1ull << ((mcnt + run) & 63);
                     mcnt += nsy;
                     const int used = b ? 1 : 1 + eval;
-                    mw <<= used; mbit += used;
+                    mw <<= used; used_all += used;
                     mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
                 }
             }
-            const uint32_t *pm = msrc + (mbit >> 5);
-            pf0 = pm[0]; pf1 = pm[1]; pf2 = pm[2];
+            if (!slow) {
+                mrb += used_all;                                        /* lands in bytes 0 .. 5: all of 8 bits */
+            } else {
+                /* byte L of the window is the first one with bits left: cum = bits up to the end of byte j */
+                uint32_t L = 0, before = 0, cum = 8 - o;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const bool ge = used_all >= cum;
+                    L += ge;
+                    before = ge ? cum : before;
+                    cum += 8 - ((n7 >> (j + 1)) & 1);
+                }
+                mrb = L ? (uint32_t)(mb + (int)L) * 8 + ((n7 >> L) & 1) + (used_all - before) : mrb + used_all;
+            }
+            const uint8_t *pm = mraw + min((int)(mrb >> 3), mlim) - 1;
+            __builtin_memcpy(&pfA, pm, 4);
+            __builtin_memcpy(&pfB, pm + 4, 4);
+            __builtin_memcpy(&pfC, pm + 8, 4);
         }
         uint64_t vwin;
         {
