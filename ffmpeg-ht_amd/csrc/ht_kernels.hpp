@@ -227,32 +227,49 @@ __device__ __forceinline__ uint32_t ht_dpp_right(uint32_t v)       /* lane i <- 
  * lengths gives its bit offset, two ds_or place it.  D is 16-byte aligned (j2k_parse.c lays the
  * block data out that way); ms[] must be zero up to the word after the last stream bit.
  * Returns the number of stream bits. */
+/* one pass over 64 dwords: `dw` is dword w0 + lane of the stream (anything where the stream has ended) */
+__device__ __forceinline__ void ht_unstuff_magsgn_step(uint32_t dw, uint32_t w0, uint32_t Pcup, uint32_t *ms, int lane,
+                                                       uint32_t &base, uint32_t &carry)
+{
+    const uint32_t wi = w0 + lane;
+    const int nv = min(max((int)Pcup - (int)(wi * 4), 0), 4);           /* stream bytes in this lane's dword */
+    dw = nv > 0 ? dw : 0u;
+    if (nv < 4) dw &= nv ? (0xFFFFFFFFu >> (32 - 8 * nv)) : 0u;
+    const uint32_t b0 = dw & 0xFF, b1 = (dw >> 8) & 0xFF, b2 = (dw >> 16) & 0xFF, b3 = dw >> 24;
+    uint32_t prev = ht_dpp_left(b3);
+    if (lane == 0) prev = carry;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)b3, 63);           /* the last byte of this pass */
+    const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
+    const uint32_t n1 = nv > 1 ? (b0 == 0xFF ? 7u : 8u) : 0u;
+    const uint32_t n2 = nv > 2 ? (b1 == 0xFF ? 7u : 8u) : 0u;
+    const uint32_t n3 = nv > 3 ? (b2 == 0xFF ? 7u : 8u) : 0u;
+    const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
+    const uint32_t chunk = b0 | (b1 << o1) | (b2 << o2) | (b3 << o3);   /* o3 <= 24: fits */
+    const uint32_t incl = wave_incl_scan_u32(tot, lane);
+    const uint32_t off = base + incl - tot, sh = off & 31;
+    if (nv > 0) {
+        atomicOr(&ms[off >> 5], chunk << sh);
+        if (sh) atomicOr(&ms[(off >> 5) + 1], chunk >> (32 - sh));
+    }
+    base += wave_last(incl);
+}
+
 __device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict__ D, uint32_t Pcup, uint32_t *ms, int lane)
 {
     const uint32_t *Dw = (const uint32_t *)D;
-    uint32_t base = 0, carry = 0;                          /* carry: the last byte of the previous pass */
-    for (uint32_t w0 = 0; w0 * 4 < Pcup; w0 += 64) {
+    uint32_t base = 0, carry = 0;
+    uint32_t pv[8];                                      /* the first 2 KB are requested at once: one memory round trip */
+#pragma unroll
+    for (int jx = 0; jx < 8; jx++) {
+        const uint32_t wi = 64 * jx + lane;
+        pv[jx] = wi * 4 < Pcup ? Dw[wi] : 0u;
+    }
+#pragma unroll
+    for (int jx = 0; jx < 8; jx++)
+        if (256u * jx < Pcup) ht_unstuff_magsgn_step(pv[jx], 64 * jx, Pcup, ms, lane, base, carry);
+    for (uint32_t w0 = 512; w0 * 4 < Pcup; w0 += 64) {
         const uint32_t wi = w0 + lane;
-        const int nv = min(max((int)Pcup - (int)(wi * 4), 0), 4);           /* stream bytes in this lane's dword */
-        uint32_t dw = nv > 0 ? Dw[wi] : 0u;
-        if (nv < 4) dw &= nv ? (0xFFFFFFFFu >> (32 - 8 * nv)) : 0u;
-        const uint32_t b0 = dw & 0xFF, b1 = (dw >> 8) & 0xFF, b2 = (dw >> 16) & 0xFF, b3 = dw >> 24;
-        uint32_t prev = ht_dpp_left(b3);
-        if (lane == 0) prev = carry;
-        carry = (uint32_t)__builtin_amdgcn_readlane((int)b3, 63);
-        const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n1 = nv > 1 ? (b0 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n2 = nv > 2 ? (b1 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n3 = nv > 3 ? (b2 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
-        const uint32_t chunk = b0 | (b1 << o1) | (b2 << o2) | (b3 << o3);   /* o3 <= 24: fits */
-        const uint32_t incl = wave_incl_scan_u32(tot, lane);
-        const uint32_t off = base + incl - tot, sh = off & 31;
-        if (nv > 0) {
-            atomicOr(&ms[off >> 5], chunk << sh);
-            if (sh) atomicOr(&ms[(off >> 5) + 1], chunk >> (32 - sh));
-        }
-        base += wave_last(incl);
+        ht_unstuff_magsgn_step(wi * 4 < Pcup ? Dw[wi] : 0u, w0, Pcup, ms, lane, base, carry);
     }
     return base;
 }
@@ -433,11 +450,16 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const int lane = threadIdx.x, hf = lane >> 5, q = lane & 31;
     const uint32_t mspitch = ms_words + 4;
     bool ok_h[2] = { false, false };
-    uint32_t lastwi_h[2] = { 0, 0 };
+    uint32_t lastwi_h[2] = { 0, 0 }, Pcup_h[2] = { 0, 0 };
+    const uint32_t *Dw_h[2] = { nullptr, nullptr };
+    uint32_t pv[2][8];                                       /* the first 2 KB of each block's MagSgn bytes */
 
-    /* ---- per block, whole wave: checks, zero-fill of blocks without passes, MagSgn un-stuffing into LDS ---- */
+    /* ---- per block, whole wave: checks, zero-fill of blocks without passes; the MagSgn bytes of both blocks are
+     * requested before either is worked on (a wave's start is a chain of dependent loads otherwise) ---- */
 #pragma unroll
     for (int hb = 0; hb < 2; hb++) {
+#pragma unroll
+        for (int jx = 0; jx < 8; jx++) pv[hb][jx] = 0;
         const int bidx = 2 * (int)blockIdx.x + hb;
         if (bidx >= nblocks) continue;
         const J2kBlock b = blocks[bidx];
@@ -450,11 +472,17 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         const int S_blk = (num_plhd / 3 + b.zbp) & 0xFF, maxbp = S_blk + 1;
         const uint32_t Lcup = b.lcup;
         const uint8_t *D = bytes + b.data_off;
+        Dw_h[hb] = (const uint32_t *)D;
+#pragma unroll
+        for (int jx = 0; jx < 8; jx++) {                     /* before Scup says where the MagSgn bytes end: Pcup <= Lcup */
+            const uint32_t wi = 64 * jx + lane;
+            if (wi * 4 < Lcup) pv[hb][jx] = Dw_h[hb][wi];
+        }
         int err = 0;
         uint32_t Scup = 0, Pcup = 0;
         if (Lcup < 2) err = HT_ERR_INVALID;
         if (!err) {
-            Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+            Scup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F)));
             if (Scup < 2 || Scup > Lcup || Scup > 4079) err = HT_ERR_INVALID;
             Pcup = Lcup - Scup;
         }
@@ -465,17 +493,30 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             if (lane == 0) status[bidx] = err;
             continue;
         }
+        ok_h[hb] = true;
+        Pcup_h[hb] = Pcup;
+    }
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++) {
+        if (!ok_h[hb]) continue;
+        const uint32_t Pcup = Pcup_h[hb];
         uint32_t *ms = ms_all + hb * mspitch;
         const uint32_t nms = (Pcup * 8 + 31) / 32 + 2;
         for (uint32_t i = lane; i <= nms + 1; i += 64) ms[i] = 0;
         __syncthreads();
-        const uint32_t ms_total = ht_unstuff_magsgn(D, Pcup, ms, lane);
+        uint32_t ms_total = 0, carry = 0;
+#pragma unroll
+        for (int jx = 0; jx < 8; jx++)
+            if (256u * jx < Pcup) ht_unstuff_magsgn_step(pv[hb][jx], 64 * jx, Pcup, ms, lane, ms_total, carry);
+        for (uint32_t w0 = 512; w0 * 4 < Pcup; w0 += 64) {
+            const uint32_t wi = w0 + lane;
+            ht_unstuff_magsgn_step(wi * 4 < Pcup ? Dw_h[hb][wi] : 0u, w0, Pcup, ms, lane, ms_total, carry);
+        }
         __syncthreads();
         for (uint32_t i = lane; i <= nms + 1; i += 64) {     /* past the end the MagSgn stream is all ones (:207-221) */
             if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
             else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
         }
-        ok_h[hb] = true;
         lastwi_h[hb] = nms - 2;                              /* words last_wi .. last_wi + 3 exist and are ones past the end */
     }
     __syncthreads();
