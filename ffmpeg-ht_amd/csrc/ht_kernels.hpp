@@ -1572,8 +1572,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         {
             const uint32_t off = vpos - (sbase << 5), kw = off >> 5, sh = off & 31;
             const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
-            const uint64_t lo = ((uint64_t)a1 << 32) | a0;
-            vwin = sh ? ((lo >> sh) | ((uint64_t)a2 << (64 - sh))) : lo;
+            vwin = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
         }
         uint32_t m = (uint32_t)msyms, mused = 0;         /* next MEL symbols, LSB first */
         uint32_t a = (uint32_t)vwin, aused = 0;         /* the two codewords need <= 14 bits */
