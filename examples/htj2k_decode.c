@@ -7,8 +7,9 @@
  *                                            (htj2k_pipe_*), frames written are those of the last round
  *   htj2k_decode -s in.j2k [out.raw]         a sequence of back-to-back codestreams / JP2 files: cut into packets by
  *                                            htj2k_splitter_* (64 KB reads), every frame decoded and written
- *   htj2k_decode -x in.mxf [out.raw]         the frame-wrapped JPEG 2000 picture elements of an MXF file
- *                                            (htj2k_mxf_next_essence; first picture track), decoded and written
+ *   htj2k_decode -x in.mxf [out.raw]         the JPEG 2000 picture elements of an MXF file (htj2k_mxf_next_essence;
+ *                                            first picture track; frame-wrapped, or clip-wrapped through the
+ *                                            splitter), decoded and written
  *
  * build: make examples   (cc examples/htj2k_decode.c -Iinclude -Lffmpeg-ht_amd -lhtj2k_amd)
  */
@@ -111,23 +112,45 @@ static int decode_mxf(const char *in, const char *outname)
     size_t pos = 0;
     uint32_t track = 0;
     htj2k_mxf_essence es;
+    htj2k_splitter *sp = NULL;
     while ((r = htj2k_mxf_next_essence(file, (size_t)size, &pos, &es)) == 1) {
-        if (es.wrapping != HTJ2K_MXF_FRAME_WRAPPED) { fprintf(stderr, "clip-wrapped essence: use -s on the element\n"); continue; }
         if (!track) track = es.track_number;
         if (es.track_number != track) continue;              /* one picture track */
-        htj2k_info info;
-        htj2k_frame fr;
-        pkt = realloc(pkt, es.size + 64);                    /* the packet with its input padding, as av_get_packet() */
-        if (!pkt) return 1;
-        memcpy(pkt, es.data, es.size);
-        memset(pkt + es.size, 0, 64);
-        if ((r = htj2k_probe(ctx, pkt, (int)es.size, &info)) < 0 || alloc_planes(&info, &fr) < 0 ||
-            (r = htj2k_decode(ctx, pkt, (int)es.size, &fr, NULL)) < 0) { fprintf(stderr, "frame %d: %d\n", nframes, r); return 1; }
-        for (int p = 0; o && p < info.nplanes; p++)
-            fwrite(fr.data[p], 1, (size_t)fr.linesize[p] * info.plane_height[p], o);
-        for (int p = 0; p < 4; p++) free(fr.data[p]);
-        printf("frame %d: %zu bytes at %zu, %dx%d pix_fmt %d\n", nframes++, es.size, es.klv_offset, info.width, info.height, info.pix_fmt);
+        /* a frame-wrapped element is one packet; a clip-wrapped one holds all codestreams back to back and is cut
+         * apart by the splitter (two passes of the loop below: the element, then the flush) */
+        const int clip = es.wrapping == HTJ2K_MXF_CLIP_WRAPPED;
+        if (clip && !sp && (r = htj2k_splitter_open(&sp)) < 0) return 1;
+        size_t off = 0;
+        for (int flush = 0; flush < 2; flush++) {
+            for (;;) {
+                const uint8_t *frame = es.data;
+                int fsize = (int)es.size;
+                if (clip) {
+                    const size_t left = flush ? 0 : es.size - off;
+                    const int chunk = left > (1u << 30) ? (1 << 30) : (int)left;
+                    int used = htj2k_splitter_parse(sp, es.data + off, chunk, &frame, &fsize);
+                    if (used < 0) { fprintf(stderr, "htj2k_splitter_parse: %d\n", used); return 1; }
+                    off += (size_t)used;
+                    if (!frame || fsize <= 0) { if (used == 0 || flush) break; else continue; }
+                }
+                htj2k_info info;
+                htj2k_frame fr;
+                pkt = realloc(pkt, (size_t)fsize + 64);      /* the packet with its input padding, as av_get_packet() */
+                if (!pkt) return 1;
+                memcpy(pkt, frame, (size_t)fsize);
+                memset(pkt + fsize, 0, 64);
+                if ((r = htj2k_probe(ctx, pkt, fsize, &info)) < 0 || alloc_planes(&info, &fr) < 0 ||
+                    (r = htj2k_decode(ctx, pkt, fsize, &fr, NULL)) < 0) { fprintf(stderr, "frame %d: %d\n", nframes, r); return 1; }
+                for (int p = 0; o && p < info.nplanes; p++)
+                    fwrite(fr.data[p], 1, (size_t)fr.linesize[p] * info.plane_height[p], o);
+                for (int p = 0; p < 4; p++) free(fr.data[p]);
+                printf("frame %d: %d bytes (element at %zu), %dx%d pix_fmt %d\n", nframes++, fsize, es.klv_offset, info.width, info.height, info.pix_fmt);
+                if (!clip || flush) break;
+            }
+            if (!clip) break;
+        }
     }
+    htj2k_splitter_close(sp);
     if (r < 0) { fprintf(stderr, "htj2k_mxf_next_essence: %d\n", r); return 1; }
     if (o) fclose(o);
     free(pkt);

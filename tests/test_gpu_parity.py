@@ -691,3 +691,9 @@ def test_c_example_program(orc, tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.count("frame ") == len(names), r.stdout
     assert out.read_bytes() == want
+    # ... and as one clip-wrapped element, cut apart by the splitter
+    mxf.write_bytes(test_mxf._mxf([b"".join(streams.get(n)[0] for n in names)], picture_key=test_mxf.PICT_J2K_CLIP, forms=("b8",)))
+    r = subprocess.run([exe, "-x", str(mxf), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.count("frame ") == len(names), r.stdout
+    assert out.read_bytes() == want
