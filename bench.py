@@ -107,6 +107,39 @@ def cpu_baseline(streams, budget_s=12.0):
                       "oracle/j2k_oracle.c (C restatement of the reference decoder incl. host parsing)" % (n, el)}
 
 
+def two_jobs_leg(dec, packets, steps):
+    """The same frames as two jobs on two HIP streams (not part of `value`, N=1 only): the instruction-bound HT kernels
+    of one job run beside the bandwidth-bound IDWT launches of the other.  It is reported beside `value` and not as
+    `value` because the IDWT launches then share the chip, and `roofline` is defined per launch (bench.py --jobs 2
+    measures everything that way)."""
+    import torch
+    jobs = [dec.job().parse_batch(packets[i::2]) for i in range(2)]
+    for job in jobs:
+        job.upload()
+    for job in jobs:
+        job.wait()
+    for _ in range(2):
+        for job in jobs:
+            job.run(7)
+    for job in jobs:
+        job.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for job in jobs:
+            job.run(7)
+        for job in jobs:
+            job.stage_ms()                                 # as in the timed region: the step's events are read
+    for job in jobs:
+        job.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for job in jobs:
+        job.free()
+    return {"value": round(steps * len(packets) * WIDTH * HEIGHT / dt / 1e6, 2), "unit": "Mpixel/s", "jobs": 2,
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4)}
+
+
 def part1_leg(dec, nframes, with_cpu):
     """the bench's 4K RGB frames coded with Part-1 (MQ) codeblocks, default mode switches, device-resident like `value`"""
     import ffmpeg_ht_amd
@@ -234,6 +267,11 @@ def main():
     frames_total = args.steps * args.batch * world
     value = frames_total * WIDTH * HEIGHT / elapsed / 1e6
 
+    # (before the host legs create and destroy their streams: the two jobs' streams should sit on hardware queues of their own)
+    two_jobs = None
+    if njobs == 1 and not args.no_e2e and world == 1 and args.batch >= 2:
+        two_jobs = two_jobs_leg(dec, per_job[0], max(5, args.steps // 2))
+
     # end-to-end rate of one frame through the plain htj2k_decode() entry (parse + H2D + kernels + D2H)
     n_e2e = 0 if (args.no_e2e or rank != 0) else 8       # the host-side legs are reported by rank 0 only
     e2e = 0.0
@@ -350,6 +388,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(streams)
         if args.part1 > 0:
             res["part1"] = part1_leg(dec, args.part1, not args.no_cpu_baseline)
+        if two_jobs:
+            res["two_jobs"] = two_jobs
         print(json.dumps(res), flush=True)
     for job in jobs:
         job.free()
