@@ -368,10 +368,13 @@ def main():
                          "min_hbm_MB_per_launch": round(idwt_launch_hbm / max(nlaunch, 1) / 1e6, 3),
                          "copy_ceiling": COPY_CEILING_GBS,
                          "sub_bands_16bit": bool(jobs[0].coef16()),
+                         "ll_bands_16bit": jobs[0].ll16() == 1,
                          "note": "achieved/frac count SURVEY 8(d)'s algorithmic bytes (4 B per sample read and written "
                                  "per level); when sub_bands_16bit is true the sub-bands really move as 2 B samples (exact "
-                                 "for this workload: every band has M_b <= 15), so frac can exceed the share of the bus "
-                                 "that is busy -- *_min_hbm_traffic and `traffic` count the bytes that really move"},
+                                 "for this workload: every band has M_b <= 15), with ll_bands_16bit the LL bands between the "
+                                 "levels too (checked on the device, second run with int32 if one does not fit), so frac can "
+                                 "exceed the share of the bus that is busy -- *_min_hbm_traffic and `traffic` count the "
+                                 "bytes that really move"},
             "stage_ms_per_step_sum_over_jobs": {"ht_decode_dequant": round(ht_ms / args.steps, 4),
                                                 "idwt": round(idwt_ms / args.steps, 4),
                                                 "mct_pack": round(pack_ms / args.steps, 4)},

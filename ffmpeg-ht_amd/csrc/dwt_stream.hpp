@@ -128,10 +128,15 @@ struct DwtFusedArgs {
 /* OUTK: what the FAST && FUSED store writes per lane and row (four pixel columns): 0 rgb24 (three 8-bit components
  * interleaved, 12 bytes), 1 rgb48 (three 16-bit components interleaved, 24 bytes), 2 one 8-bit plane (4 bytes),
  * 3 one 16-bit plane (8 bytes) */
+/* !FUSED with OUTK == 16: the level's output -- the next level's LL band -- is written as 16-bit samples too (same
+ * element offsets, the buffer read as int16_t), and *ovf is set when a sample does not fit: an LL band of a real
+ * picture stays in the picture's range, but nothing bounds what crafted or corrupt coefficients add up to.  The host
+ * then runs the transform again with 32-bit LL bands (htj2k_device.hip, job_settle). */
 template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
-                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by,
+                 int *__restrict__ ovf = nullptr, int ovf_bits = 16)
 {
     using O = LiftOps<TYPE>;
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
@@ -278,6 +283,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     constexpr int NW = OUTK == 0 ? 3 : OUTK == 1 ? 6 : OUTK == 2 ? 1 : 2;   /* dwords a lane stores per row */
     uint32_t wk[2][6] = { { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0, 0 } };   /* fast fused path: the two rows' store data ... */
     uintptr_t ak[2] = { 0, 0 };                              /* ... and addresses of the last step */
+    uint32_t ovf_acc = 0;                                    /* OUTK == 16: a stored sample did not fit 16 bits */
     auto emit = [&](int row_abs, uint32_t (&val)[NC][4], int slot) {
         const int y = row_abs - g.mv;
         if (row_abs < a_first || row_abs > a_last) return;                 /* wave-uniform */
@@ -288,7 +294,20 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 #pragma unroll
                     for (int k = 0; k < 4; k++) val[c][k] = (uint32_t)((int32_t)((int32_t)val[c][k] + 128) >> 8);   /* :534-536 */
             }
-            if (!FUSED) {
+            if (!FUSED && OUTK == 16) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    uint16_t *p = (uint16_t *)out_base + A[c].out_off + (size_t)y * A[c].out_stride + xa;
+                    /* v + 0x8000 < 0x10000 exactly for v in [-32768, 32767] (ovf_bits = 16; fewer bits: the tests' way to
+                     * make ordinary frames take the overflow path) */
+                    const uint32_t hb = 1u << (ovf_bits - 1);
+                    const uint32_t t = (val[c][0] + hb) | (val[c][1] + hb) | (val[c][2] + hb) | (val[c][3] + hb);
+                    if (lane_ok) {
+                        ovf_acc |= t >> ovf_bits;
+                        *(uint2 *)p = make_uint2((val[c][0] & 0xFFFFu) | (val[c][1] << 16), (val[c][2] & 0xFFFFu) | (val[c][3] << 16));
+                    }
+                }
+            } else if (!FUSED) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     uint32_t *p = out_base + A[c].out_off + (size_t)y * A[c].out_stride + xa;
@@ -465,6 +484,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         step(ye + 2 * dir, LB, HB);
         if (dir * (ye + 4 * dir - s_last) > 0) break;
     }
+    if (!FUSED && OUTK == 16 && ovf_acc) atomicOr(ovf, 1);
 }
 
 /* Which waves may take the fast path: conditions on the level geometry and, for the fused
@@ -567,6 +587,18 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
     idwt_stream_body<TYPE, 1, false, FASTONLY, C16, LL16>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by);
+}
+
+/* plain 5/3 level of a job with 16-bit sub-bands whose LL bands are 16-bit as well, in and out */
+__global__ void __launch_bounds__(64)
+k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
+                   const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G,
+                   int *__restrict__ ovf, int ovf_bits)
+{
+    int bx, by, bz;
+    if (!stream_strip(G, bx, by, bz)) return;
+    const DwtTileArgs A[1] = { args[bz] };
+    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by, ovf, ovf_bits);
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */

@@ -87,6 +87,9 @@ struct htj2k_ctx {
                                         * 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
+    int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
+    int ll16 = 1;                      /* 1: such jobs also keep the LL bands between the IDWT levels as int16_t (overflow is detected
+                                        * on the device and the transform run again with 32-bit LL bands, job_settle) */
     int coef16 = 1;                    /* 1: reversible jobs whose coefficients fit 16 bits keep them as int16_t between the
                                         * block decoder and the IDWT (see coef16_ok) */
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
@@ -140,6 +143,10 @@ struct htj2k_job {
     bool pair_ok = false;              /* ... and k_ht_decode_pair's dword stores are aligned: even widths, strides, offsets */
     bool coef16_ok = false;
     bool coef_is16 = false;            /* what the last HT stage run actually wrote */
+    bool ll16_run = false;             /* the last IDWT run wrote its LL bands as int16_t ... */
+    bool ll16_checked = true;          /* ... and the overflow flag behind d_status has been looked at since */
+    bool force_ll32 = false;           /* the re-run after an overflow */
+    int ll16_fallbacks = 0;
     int nht = 0;
     std::vector<MqWave> mqwaves;       /* one per 64 Part-1 blocks */
     size_t mq_scratch_units = 0;       /* 512-byte row slots of k_mq_decode's scratch */
@@ -253,6 +260,8 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
     if (m && !strcmp(m, "tile2")) c->idwt_mode = 2;
     if (m && !strcmp(m, "stream")) c->idwt_mode = 3;
+    const char *l16 = getenv("HTJ2K_LL16");
+    if (l16) c->ll16 = atoi(l16) ? 1 : 0;
     const char *fz = getenv("HTJ2K_FUSE");
     if (fz) c->fuse_pack = atoi(fz) != 0;
     *out = c;
@@ -276,6 +285,8 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
     if (!strcmp(name, "reduction_factor")) { c->opts.reduction_factor = value; return 0; }
     return HTJ2K_ERR_EINVAL;
@@ -1046,6 +1057,14 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
 template <int TYPE>
 static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
 {
+    if (TYPE == J2K_DWT53 && j->ll16_run && c->idwt_mode >= 3 && L.min_l >= 2) {    /* 16-bit sub-bands and LL bands, in and out */
+        const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
+        const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count);
+        hipLaunchKernelGGL(k_idwt_stream_ll16, dim3(8 * G.per_xcd), dim3(64), 0, j->stream,
+                           (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
+                           (int *)j->d_status.p + j->blocks.size(), c->ll16_test_bits);
+        return;
+    }
     launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
                               j->stream, ll, (const uint32_t *)j->d_coef.p, out, L.all_fast,
                               j->coef_is16 ? (L.level == 0 ? 2 : 1) : 0);   /* 16-bit sub-bands; at level 0 the LL band too */
@@ -1062,7 +1081,7 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
 #define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G)
     if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: every fused launch is a fast-store one */
-        const bool l0 = L.level == 0;
+        const bool l0 = L.level == 0 || j->ll16_run;      /* the LL band is 16-bit: the block decoder's, or the level below wrote it so */
         if (L.outk == 0) { if (l0) FUSED_FAST(3, true, true, 0); else FUSED_FAST(3, true, false, 0); }
         else if (L.outk == 1) { if (l0) FUSED_FAST(3, true, true, 1); else FUSED_FAST(3, true, false, 1); }
         else if (L.outk == 2) { if (l0) FUSED_FAST(1, true, true, 2); else FUSED_FAST(1, true, false, 2); }
@@ -1118,7 +1137,8 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
          * (alg_bytes = 8 per sample); the fused level writes the packed pixels instead (hbm_bytes = 4 + out per
          * sample).  With 16-bit sub-bands three quarters of the reads are 2 bytes (all of them at level 0). */
         double hb = L.nc ? L.hbm_bytes : L.alg_bytes;
-        if (j->coef_is16) hb -= L.alg_bytes / 8.0 * (L.level == 0 ? 2.0 : 1.5);
+        if (j->coef_is16) hb -= L.alg_bytes / 8.0 * ((L.level == 0 || j->ll16_run) ? 2.0 : 1.5);
+        if (j->ll16_run && !L.nc) hb -= L.alg_bytes / 8.0 * 2.0;            /* ... and writes 2 instead of 4 bytes per sample */
         j->lev_hbm.push_back(hb);
     }
     return 0;
@@ -1132,7 +1152,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
     HIP_TRY(c, hipSetDevice(c->device));
     if (mask & 1) {
         HIP_TRY(c, hipEventRecord(j->ev[2], j->stream));
-        if (nall) HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, (size_t)nall * sizeof(int), j->stream));
+        if (nall) HIP_TRY(c, hipMemsetAsync(j->d_status.p, 0, ((size_t)nall + 1) * sizeof(int), j->stream));   /* + the LL overflow flag */
         if (nall > nblocks) {
             const uint32_t area = mq_lds_area(j->mq_planes);
             unsigned nwide = 0;                                      /* waves holding a block wider than 64 columns */
@@ -1228,6 +1248,9 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         if (!(mask & 1)) HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
         HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
         if (mask & 2) {
+            /* coef16_ok has checked that every level of every plane is a FASTONLY streaming launch and every plane ends fused */
+            j->ll16_run = c->ll16 && j->coef_is16 && fuse && use_tile && !j->force_ll32;
+            j->ll16_checked = !j->ll16_run;
             int r = run_idwt(c, j, use_tile, fuse);
             if (r < 0) return r;
             HIP_TRY(c, hipGetLastError());
@@ -1251,12 +1274,34 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
 
 extern "C" int htj2k_job_run(htj2k_ctx *c, htj2k_job *j) { return htj2k_job_run_stages(c, j, 7); }
 
-extern "C" int htj2k_job_wait(htj2k_ctx *c, htj2k_job *j)
+/* Wait for the job's stream; if its last IDWT run kept the LL bands as 16-bit samples, look at the overflow flag once and,
+ * if a sample did not fit, run the transform again with 32-bit LL bands (the sub-bands are still there) */
+static int job_settle(htj2k_ctx *c, htj2k_job *j)
 {
-    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(j->stream));
+    if (j->ll16_checked) return 0;
+    j->ll16_checked = true;
+    int flag = 0;
+    HIP_TRY(c, hipMemcpy(&flag, (const int *)j->d_status.p + j->blocks.size(), sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return 0;
+    clog(c, LOG_INFO, "an LL band left the 16-bit range: inverse DWT run again with 32-bit LL bands\n");
+    j->ll16_fallbacks++;
+    j->force_ll32 = true;
+    const int r = htj2k_job_run_stages(c, j, 6);
+    j->force_ll32 = false;
+    if (r < 0) return r;
     HIP_TRY(c, hipStreamSynchronize(j->stream));
     return 0;
 }
+
+extern "C" int htj2k_job_wait(htj2k_ctx *c, htj2k_job *j)
+{
+    if (!c || !j) return HTJ2K_ERR_EINVAL;
+    return job_settle(c, j);
+}
+
+/* 0: the last run's LL bands were 32-bit, 1: 16-bit, 2: 16-bit, overflowed and run again with 32 (after htj2k_job_wait) */
+extern "C" int htj2k_job_ll16(const htj2k_job *j) { return j ? (j->ll16_run ? 1 : (j->ll16_fallbacks ? 2 : 0)) : HTJ2K_ERR_EINVAL; }
 
 extern "C" int htj2k_job_stage_ms(htj2k_ctx *c, htj2k_job *j, float *ms_ht, float *ms_idwt, float *ms_pack)
 {
@@ -1331,6 +1376,7 @@ extern "C" int htj2k_job_download_frame(htj2k_ctx *c, htj2k_job *j, int f, htj2k
     if (!c || !j || f < 0 || f >= j->nframes || !frame) return HTJ2K_ERR_EINVAL;
     const FrameSlot &F = j->frames[f];
     const J2kPlan *pl = F.plan;
+    if (!j->ll16_checked) { const int r = job_settle(c, j); if (r < 0) return r; }
     for (int p = 0; p < pl->info.nplanes; p++) {
         const int rowbytes = pl->info.plane_width[p] * pl->info.plane_bytes_per_sample[p];
         if (!frame->data[p] || frame->linesize[p] < rowbytes) return HTJ2K_ERR_EINVAL;

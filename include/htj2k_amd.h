@@ -152,6 +152,11 @@ int  htj2k_job_idwt_launches(htj2k_ctx *ctx, htj2k_job *job, float *ms, double *
  * (exact: reversible 5/3 jobs whose every band has M_b <= 15, rgb24 output, all levels of even geometry; knob
  * "coef16", default on).  The reference holds them as int32 (comp->i_data, jpeg2000.c:499-511). */
 int  htj2k_job_coef16(const htj2k_job *job);
+/* 0: the last run held the LL bands between the IDWT levels as int32 (as the reference, jpeg2000dwt.c:539-581);
+ * 1: as 16-bit samples (knob "ll16", jobs with 16-bit sub-bands only); 2: it did, a sample of an LL band did not fit
+ * -- only crafted or corrupt coefficients do that -- and htj2k_job_wait / _download ran the transform again with
+ * int32 LL bands before handing out the frames */
+int  htj2k_job_ll16(const htj2k_job *job);
 int  htj2k_job_idwt_hbm_bytes(htj2k_ctx *ctx, htj2k_job *job, double *bytes, int cap);
 /* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
 int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
@@ -215,6 +220,8 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
  *   "coef16"      1 (default): jobs that qualify keep the sub-bands as 16-bit samples (htj2k_job_coef16)
  *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
+ *   "ll16"        1 (default): such jobs also hold the LL bands between the IDWT levels as 16-bit samples, with a check
+ *                 on the device and a second run with int32 LL bands should one not fit (htj2k_job_ll16)
  *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
  *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);

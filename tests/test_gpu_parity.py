@@ -459,6 +459,73 @@ def test_coef16_rejected_block_is_zeroed(dec, orc):
     job.free()
 
 
+def test_ll16_jobs_match_int32_ll_bands_and_the_oracle(dec, orc):
+    """knob "ll16" (default on): jobs with 16-bit sub-bands also write the LL bands between the IDWT levels as 16-bit samples: same
+    pixels as with int32 LL bands, as the oracle, as the source; the pipeline entry points take the same path"""
+    try:
+        for key, img, data in _coef16_streams():
+            info_o, planes_o, _ = orc.decode(data)
+            res = {}
+            for ll16 in (1, 0):
+                dec.set_int("ll16", ll16)
+                job = dec.job().parse_batch([data, data]).upload().run().wait()
+                assert job.coef16() and job.block_errors() == 0
+                assert job.ll16() == ll16, (key, ll16, job.ll16())
+                res[ll16] = [job.download_frame(f)[1] for f in range(2)]
+                job.free()
+            for f in range(2):
+                for a, b, d in zip(res[1][f], res[0][f], planes_o):
+                    assert np.array_equal(a, b) and np.array_equal(a, d), key
+            dec.set_int("ll16", 1)
+            info, planes, _, st = dec.decode(data)                    # htj2k_decode: run + download, no wait in between
+            assert all(np.array_equal(a, d) for a, d in zip(planes, planes_o)), key
+    finally:
+        dec.set_int("ll16", 1)
+
+
+def test_ll16_overflow_runs_the_transform_again(dec, orc):
+    """Nothing bounds the LL bands of crafted or corrupt coefficient data, so the level kernels flag a sample that does
+    not fit and the job repeats the IDWT with int32 LL bands before it hands out frames.  A stream produced by a forward
+    transform cannot get there (every intermediate LL band is a low-pass of the picture), so the knob "ll16_test_bits"
+    lowers the limit: with 6 bits ordinary frames overflow, and must come out exactly as before -- from wait + download,
+    from download alone (htj2k_decode) and from the pipeline."""
+    try:
+        dec.set_int("ll16", 1)
+        for key, img, data in _coef16_streams()[:4]:
+            info_o, planes_o, _ = orc.decode(data)
+            for bits, want in ((16, 1), (6, 2)):
+                dec.set_int("ll16_test_bits", bits)
+                job = dec.job().parse_batch([data, data]).upload().run().wait()
+                assert job.coef16() and job.ll16() == want, (key, bits, job.ll16())
+                for f in range(2):
+                    assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(f)[1], planes_o)), (key, bits)
+                job.run().wait()                                  # and again: the job is back on 16-bit LL bands, overflows again
+                assert job.ll16() == want
+                assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(1)[1], planes_o)), (key, bits)
+                job.free()
+                info, planes, _, st = dec.decode(data)
+                assert all(np.array_equal(a, d) for a, d in zip(planes, planes_o)), (key, bits)
+        dec.set_int("ll16_test_bits", 6)
+        key, img, data = _coef16_streams()[1]
+        info_o, planes_o, _ = orc.decode(data)
+        pipe = dec.pipe(batch=3, depth=3)
+        got = 0
+        for i in range(7):
+            assert pipe.send(data)
+        pipe.flush()
+        while True:
+            r = pipe.receive()
+            if r is None:
+                break
+            assert all(np.array_equal(a, d) for a, d in zip(r[1], planes_o))
+            got += 1
+        pipe.close()
+        assert got == 7
+    finally:
+        dec.set_int("ll16_test_bits", 16)
+        dec.set_int("ll16", 1)
+
+
 # ---------------------------------------------------------------- Part-1 (MQ-coded) blocks: k_mq_decode
 OPJ = np.load(os.path.join(HERE, "golden", "opj_part1.npz"))
 
