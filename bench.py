@@ -387,7 +387,7 @@ def main():
                      "pipeline": "htj2k_pipe: 96 frames after 24 warm-up, batches of 8, 3 in flight, pageable packets in, "
                                  "frames out into pageable / page-locked (htj2k_host_alloc) planes"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 run only
             res["cpu_baseline"] = cpu_baseline(streams)
         if args.part1 > 0:
             res["part1"] = part1_leg(dec, args.part1, not args.no_cpu_baseline)
