@@ -273,7 +273,7 @@ def main():
         two_jobs = two_jobs_leg(dec, per_job[0], max(5, args.steps // 2))
 
     # end-to-end rate of one frame through the plain htj2k_decode() entry (parse + H2D + kernels + D2H)
-    n_e2e = 0 if (args.no_e2e or rank != 0) else 8       # the host-side legs are reported by rank 0 only
+    n_e2e = 0 if (args.no_e2e or rank != 0 or world > 1) else 8       # the host-side legs: rank 0 of the N = 1 run only
     e2e = 0.0
     if n_e2e:
         pk1 = [m.packet(x) for x in streams]
@@ -287,7 +287,7 @@ def main():
     # the asynchronous pipeline (htj2k_pipe_*): packets in host memory -> frames in host memory, with host
     # parsing (several threads), H2D, kernels and D2H of different batches overlapping
     pipe_rate = pipe_rate_pinned = pipe_rate_device = 0.0
-    if not args.no_e2e and rank == 0:
+    if not args.no_e2e and rank == 0 and world == 1:
         info0 = dec.probe(streams[0])
         pk = [m.packet(x) for x in streams]
 
