@@ -26,7 +26,9 @@ tools/ubench/membw: tools/ubench/membw.hip
 tools/ubench/occupancy: tools/ubench/occupancy.hip $(wildcard $(CSRC)/*.hpp)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
-$(CSRC)/j2k_parse.o: $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h include/htj2k_amd.h
+# host front-end: codestream syntax, geometry + Tier-2, plan assembly
+HOSTOBJ := $(CSRC)/j2k_syntax.o $(CSRC)/j2k_tier2.o $(CSRC)/j2k_plan.o
+$(HOSTOBJ): %.o: %.c $(CSRC)/j2k_host.h $(CSRC)/j2k_plan.h include/htj2k_amd.h
 	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
 
 # -ffp-contract=off: the reference objects contain no FMA; 9/7 parity needs
@@ -43,14 +45,15 @@ $(CSRC)/j2k_split.o: $(CSRC)/j2k_split.c include/htj2k_amd.h
 $(CSRC)/j2k_mxf.o: $(CSRC)/j2k_mxf.c include/htj2k_amd.h
 	$(CC) $(CFLAGS) -std=gnu11 -c $< -o $@
 
-$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(CSRC)/j2k_parse.o $(CSRC)/j2k_split.o $(CSRC)/j2k_mxf.o
+$(PKG)/libhtj2k_amd.so: $(CSRC)/htj2k_device.o $(CSRC)/htj2k_pipe.o $(HOSTOBJ) $(CSRC)/j2k_split.o $(CSRC)/j2k_mxf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
-# The oracle links the same host parser object as the product (parsing is not on the
-# judged hot path) and its own CPU restatement of the reference's compute.
-oracle/libj2k_oracle.so: oracle/j2k_oracle.c oracle/j2k_oracle_mq.c $(CSRC)/j2k_parse.c $(CSRC)/j2k_plan.h $(CSRC)/ht_cxtvlc_rows.h
+# The oracle is self-contained: its own parser (oracle/j2k_oracle_parse.c, a close restatement of the
+# reference's) and its own CPU restatement of the reference's compute.  Nothing of csrc/ is compiled in
+# except the constant CxtVLC rows.
+oracle/libj2k_oracle.so: oracle/j2k_oracle.c oracle/j2k_oracle_mq.c oracle/j2k_oracle_parse.c oracle/j2k_oracle_split.c oracle/j2k_oracle_plan.h $(CSRC)/ht_cxtvlc_rows.h
 	$(CC) -O3 -fno-math-errno -fno-signed-zeros -fno-tree-vectorize -ffp-contract=off -g -Wall -Wextra -fPIC -std=gnu11 \
-	    -shared -o $@ oracle/j2k_oracle.c oracle/j2k_oracle_mq.c $(CSRC)/j2k_parse.c -lm
+	    -shared -o $@ oracle/j2k_oracle.c oracle/j2k_oracle_mq.c oracle/j2k_oracle_parse.c oracle/j2k_oracle_split.c -lm
 
 tools/vecgen/libhtj2k_vecgen.so: tools/vecgen/htj2k_enc.c tools/vecgen/htj2k_enc.h $(CSRC)/ht_cxtvlc_rows.h
 	$(CC) $(CFLAGS) -std=gnu11 -shared -o $@ $< -lm

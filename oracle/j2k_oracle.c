@@ -26,9 +26,10 @@
  * HT features none of these cover (placeholder passes, ROI shift) are "parity
  * unpinned" and say so in their tests.
  *
- * Marker / Tier-2 parsing is shared with the product (ffmpeg-ht_amd/csrc/j2k_parse.c
- * is compiled into this library too): host parsing is not on the judged path, and the
- * KATs + OpenJPEG cross-checks cover it end to end.
+ * Marker / Tier-2 parsing: oracle/j2k_oracle_parse.c, the oracle's OWN parser -- a close
+ * restatement of jpeg2000dec.c:197-1869 / jpeg2000.c:214-577 (the product's host parser,
+ * ffmpeg-ht_amd/csrc/j2k_syntax.c + j2k_tier2.c + j2k_plan.c, is an independent
+ * implementation; tests/test_plan_equality.py compares the two descriptor tables).
  */
 #include <limits.h>
 #include <math.h>
@@ -37,7 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../ffmpeg-ht_amd/csrc/j2k_plan.h"
+#include "j2k_oracle_plan.h"
 #include "../ffmpeg-ht_amd/csrc/ht_cxtvlc_rows.h"
 
 #define ORC_EXPORT __attribute__((visibility("default")))
@@ -895,7 +896,7 @@ typedef struct OrcFrame {
 ORC_EXPORT OrcFrame *orc_frame_new(void)
 {
     OrcFrame *f = (OrcFrame *)calloc(1, sizeof(*f));
-    if (f) f->parser = j2k_parser_new();
+    if (f) f->parser = orc_parser_new();
     if (f && !f->parser) { free(f); return NULL; }
     return f;
 }
@@ -903,7 +904,7 @@ ORC_EXPORT OrcFrame *orc_frame_new(void)
 ORC_EXPORT void orc_frame_free(OrcFrame *f)
 {
     if (!f) return;
-    j2k_parser_free(f->parser);
+    orc_parser_free(f->parser);
     free(f->coef);
     free(f);
 }
@@ -917,7 +918,7 @@ ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size
     uint8_t *scratch = NULL;
 
     free(f->coef); f->coef = NULL; f->n_block_errors = 0;
-    ret = j2k_parse(f->parser, pkt, size, opts, 0, &f->plan);
+    ret = orc_parse(f->parser, pkt, size, opts, 0, &f->plan);
     if (ret < 0)
         return ret;
     pl = f->plan;
@@ -1051,7 +1052,7 @@ ORC_EXPORT int orc_decode(OrcFrame *f, const uint8_t *pkt, int size, const htj2k
 ORC_EXPORT int orc_probe(OrcFrame *f, const uint8_t *pkt, int size, const htj2k_opts *opts, htj2k_info *info)
 {
     const J2kPlan *pl;
-    int ret = j2k_parse(f->parser, pkt, size, opts, 1, &pl);
+    int ret = orc_parse(f->parser, pkt, size, opts, 1, &pl);
     if (ret < 0) return ret;
     *info = pl->info;
     return 0;

@@ -19,7 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../ffmpeg-ht_amd/csrc/j2k_plan.h"
+#include "j2k_oracle_plan.h"
 
 #define ORC_EXPORT __attribute__((visibility("default")))
 

@@ -1,16 +1,17 @@
 /*
- * j2k_parse.c -- host side of the HTJ2K decode path: codestream markers, JP2
- * wrapper, Tier-2 packet headers and tile/band/precinct/codeblock geometry,
- * distilled into a flat J2kPlan for the device.
+ * j2k_oracle_parse.c -- TEST INFRASTRUCTURE ONLY: the oracle's codestream parser.
  *
- * This restates, with its own data layout (one arena, flat tables, no per-node
- * mallocs), the serial host work the reference does before tile_codeblocks():
+ * A close, branch-for-branch restatement of the serial host work the reference does before
+ * tile_codeblocks():
  *   marker segments      libavcodec/jpeg2000dec.c:197-1014, 2425-2637
  *   JP2 box walk         libavcodec/jpeg2000dec.c:2658-2805
  *   Tier-2               libavcodec/jpeg2000dec.c:70-131, 1073-1869
  *   geometry, step sizes libavcodec/jpeg2000.c:214-577, jpeg2000dwt.c:539-581
- * Nothing here touches the GPU; the same object file is linked into the product
- * library and (tests only) into the CPU oracle.
+ * with the reference's tree of tile / component / resolution / band / precinct / codeblock
+ * nodes.  It was the product's parser in round 1; since round 2 the product has its own,
+ * independently structured implementation (ffmpeg-ht_amd/csrc/j2k_syntax.c, j2k_tier2.c,
+ * j2k_plan.c) and this file is the checker it is compared against
+ * (tests/test_plan_equality.py).  Nothing under ffmpeg-ht_amd/ links it.
  */
 #include <limits.h>
 #include <math.h>
@@ -18,7 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "j2k_plan.h"
+#include "j2k_oracle_plan.h"
 
 #define MAX_RESLEVELS   34      /* JPEG2000_MAX_RESLEVELS, jpeg2000.h:82 */
 #define MAX_DECLEVELS   33
@@ -281,7 +282,7 @@ static const J2kPixDesc pixdescs[HTJ2K_PIX_NB] = {
     [HTJ2K_PIX_YUVA444P16] = PD("yuva444p16le",4,0,0,1,0,16,16,16,16, 4,2),
     [HTJ2K_PIX_XYZ12]      = PD("xyz12le",    3,0,0,0,0, 12,12,12, 0, 1,2),
 };
-const J2kPixDesc *j2k_pix_desc(int pix_fmt)
+const J2kPixDesc *orc_pix_desc(int pix_fmt)
 {
     if (pix_fmt < 0 || pix_fmt >= HTJ2K_PIX_NB) return NULL;
     return &pixdescs[pix_fmt];
@@ -311,7 +312,7 @@ static const int all_fmts[]  = { RGB_FMTS, GRAY_FMTS, YUV_FMTS, HTJ2K_PIX_XYZ12 
 /* pix_fmt_match, jpeg2000dec.c:133-166 (note the deliberate switch fall-through) */
 static int pix_fmt_match(int pix_fmt, int components, int bpc, uint32_t log2_chroma_wh, int pal8)
 {
-    const J2kPixDesc *d = j2k_pix_desc(pix_fmt);
+    const J2kPixDesc *d = orc_pix_desc(pix_fmt);
     int match = 1;
     if (!d || d->nb_components != components)
         return 0;
@@ -2380,7 +2381,7 @@ static int jp2_find_codestream(J2kParser *s)
 /* ------------------------------------------------------------------ plan building */
 static void fill_info(J2kParser *s, htj2k_info *info)
 {
-    const J2kPixDesc *d = j2k_pix_desc(s->pix_fmt);
+    const J2kPixDesc *d = orc_pix_desc(s->pix_fmt);
     int p;
     memset(info, 0, sizeof(*info));
     info->width  = s->dimx;
@@ -2417,7 +2418,7 @@ static void fill_info(J2kParser *s, htj2k_info *info)
 static int build_plan(J2kParser *s)
 {
     J2kPlan *pl = &s->plan;
-    const J2kPixDesc *pd = j2k_pix_desc(s->pix_fmt);
+    const J2kPixDesc *pd = orc_pix_desc(s->pix_fmt);
     int ntiles = s->numXtiles * s->numYtiles;
     int tileno, compno, reslevelno, bandno, precno, cblkno;
     size_t nblocks = 0, nbytes = 0, nsamples = 0;
@@ -2693,32 +2694,32 @@ static int build_plan(J2kParser *s)
 }
 
 /* ------------------------------------------------------------------ public */
-J2kParser *j2k_parser_new(void)
+J2kParser *orc_parser_new(void)
 {
     return (J2kParser *)calloc(1, sizeof(J2kParser));
 }
 
-void j2k_parser_free(J2kParser *p)
+void orc_parser_free(J2kParser *p)
 {
     if (!p) return;
     arena_free(&p->arena);
     free(p);
 }
 
-void j2k_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque)
+void orc_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque)
 {
     p->log = fn;
     p->log_opaque = opaque;
 }
 
-void j2k_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque)
+void orc_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque)
 {
     p->bytes_alloc = fn;
     p->bytes_alloc_opaque = opaque;
 }
 
 /* jpeg2000_decode_frame, jpeg2000dec.c:2825-2908, up to (not including) execute2() */
-int j2k_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts,
+int orc_parse(J2kParser *s, const uint8_t *pkt, int size, const htj2k_opts *opts,
               int headers_only, const J2kPlan **plan)
 {
     Arena arena = s->arena;

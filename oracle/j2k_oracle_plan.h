@@ -1,20 +1,19 @@
 /*
- * j2k_plan.h -- the "decode plan": everything the host parser distils from one
- * codestream for the device.  Produced by the host front-end
- * (j2k_syntax.c, j2k_tier2.c, j2k_plan.c), consumed by the HIP layer (htj2k_device.hip).
- * (The CPU oracle has its own parser and its own frozen copy of these types,
- * oracle/j2k_oracle_plan.h; tests/native/plan_diff.c compares the two.)
+ * j2k_oracle_plan.h -- TEST INFRASTRUCTURE ONLY.  The oracle's own copy of the "decode plan"
+ * types (the descriptor layout of ffmpeg-ht_amd/csrc/j2k_plan.h as of round 1, frozen here so
+ * that the product header can evolve): what oracle/j2k_oracle_parse.c distils from one
+ * codestream and oracle/j2k_oracle.c decodes on the CPU.
  *
  * Reference types this is distilled from: Jpeg2000Cblk (libavcodec/jpeg2000.h:183-205),
  * Jpeg2000Band (:217-223), Jpeg2000Component (:233-241), DWTContext
  * (libavcodec/jpeg2000dwt.h:44-52), Jpeg2000DecoderContext (jpeg2000dec.h:73-123).
  */
-#ifndef J2K_PLAN_H
-#define J2K_PLAN_H
+#ifndef J2K_ORACLE_PLAN_H
+#define J2K_ORACLE_PLAN_H
 
 #include <stddef.h>
 #include <stdint.h>
-#include "../../include/htj2k_amd.h"
+#include "../include/htj2k_amd.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -89,15 +88,6 @@ typedef struct J2kTileComp {
     int32_t mct;                 /* 1 if this tile's codsty[0].mct and comp < 3 and mct_decode() accepts it */
 } J2kTileComp;
 
-/* One piece of a code-block's byte string: `len` bytes at offset `src` of the packet (or of J2kPlan.lit with
- * J2K_SEG_LIT) go to offset `dst` of the byte pool; with J2K_SEG_TERM the bytes 0xFF 0xFF follow them (a terminated
- * Part-1 segment, jpeg2000dec.c:1510-1516).  The pieces of block i are segs[blk_seg0[i] .. blk_seg0[i + 1]), in pool
- * order.  With this table the byte pool can be put together anywhere -- by j2k_plan_gather() on the host, or by
- * k_gather on the device from the uploaded packet (the host then never touches the code-block bytes). */
-typedef struct J2kSeg { uint32_t src, dst, len, flags; } J2kSeg;
-#define J2K_SEG_TERM 1
-#define J2K_SEG_LIT  2
-
 typedef struct J2kPlan {
     htj2k_info info;
     int32_t bytes_consumed;      /* bytestream2_tell at return (jpeg2000dec.c:2903) */
@@ -109,15 +99,8 @@ typedef struct J2kPlan {
     J2kTileComp *tilecomps;
     int32_t nblocks;
     J2kBlock *blocks;
-    uint8_t *bytes;              /* concatenated codeblock bytes; NULL when the parser does not gather (j2k_parser_set_gather) */
+    uint8_t *bytes;              /* concatenated codeblock bytes */
     size_t   nbytes;
-    const uint8_t *pkt;          /* the packet the plan was made from (borrowed) */
-    int32_t  pkt_size;
-    J2kSeg  *segs;               /* gather table: how `bytes` is put together from `pkt` and `lit` */
-    uint32_t nsegs;
-    uint32_t *blk_seg0;          /* nblocks + 1 entries */
-    uint8_t *lit;                /* bytes that are not in the packet: 0xFF 0xFF, Part-1 trailers */
-    uint32_t nlit;
     size_t   nsamples;           /* total samples of all planes (frame coefficient buffer size) */
     uint32_t max_lcup, max_lref; /* sizing of the per-wave LDS windows */
     /* over the coded blocks with a valid cleanup segment: longest MagSgn (Pcup) and VLC/MEL (Scup) parts,
@@ -139,25 +122,19 @@ typedef struct J2kParser J2kParser;   /* reusable arena; not thread-safe */
 
 typedef void (*j2k_log_fn)(void *opaque, int level, const char *msg);
 
-J2kParser *j2k_parser_new(void);
-void       j2k_parser_free(J2kParser *p);
-void       j2k_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque);
+J2kParser *orc_parser_new(void);
+void       orc_parser_free(J2kParser *p);
+void       orc_parser_set_log(J2kParser *p, j2k_log_fn fn, void *opaque);
 /* where J2kPlan.bytes of the next plans lives: fn(opaque, n) returns a buffer of >= n bytes that stays
  * valid until its next call (the device layer hands out pinned host memory); NULL fn = the parser's arena */
 typedef void *(*j2k_bytes_alloc_fn)(void *opaque, size_t n);
-void       j2k_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque);
-
-/* on (default): j2k_parse fills J2kPlan.bytes; off: only the gather table is made and no code-block byte is read
- * except the two that hold Scup */
-void       j2k_parser_set_gather(J2kParser *p, int on_host);
-/* the byte pool of a plan, nbytes + 64 bytes, written to dst (what the parser does itself when gathering is on) */
-void       j2k_plan_gather(const J2kPlan *plan, uint8_t *dst);
+void       orc_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void *opaque);
 
 /* Full parse: markers + all packets.  `headers_only` stops after the main
  * header (info valid, no blocks), like skip_frame >= AVDISCARD_ALL
  * (jpeg2000dec.c:2871-2874).  The plan is owned by the parser and valid until
  * the next call.  Returns 0 or a negative HTJ2K_ERR_*. */
-int j2k_parse(J2kParser *p, const uint8_t *pkt, int size, const htj2k_opts *opts,
+int orc_parse(J2kParser *p, const uint8_t *pkt, int size, const htj2k_opts *opts,
               int headers_only, const J2kPlan **plan);
 
 /* pix-fmt facts shared by parser, device layer and oracle */
@@ -171,7 +148,7 @@ typedef struct J2kPixDesc {
     uint8_t nplanes;
     uint8_t bytes;      /* bytes per sample */
 } J2kPixDesc;
-const J2kPixDesc *j2k_pix_desc(int pix_fmt);
+const J2kPixDesc *orc_pix_desc(int pix_fmt);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ def test_parser_survives_mutations_under_asan_ubsan(tmp_path):
     cmd = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ffmpeg-ht_amd", "csrc"),
            "-o", str(exe), os.path.join(HERE, "native", "fuzz_parse.c"),
-           os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_parse.c"), os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_split.c"),
+           os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_syntax.c"), os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_tier2.c"),
+           os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_plan.c"), os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_split.c"),
            os.path.join(ROOT, "ffmpeg-ht_amd", "csrc", "j2k_mxf.c"), "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "sanitize" in r.stderr:
