@@ -75,7 +75,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
            "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
-           "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_frame_info", "htj2k_job_download_frame",
+           "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_host_ms", "htj2k_job_frame_info", "htj2k_job_download_frame",
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
@@ -146,6 +146,12 @@ class Job:
 
     def num_frames(self):
         return _check(self.dec.L.htj2k_job_num_frames(self.h), "htj2k_job_num_frames")
+
+    def host_ms(self):
+        """(parse ms, staging-copy ms) per frame of the last parse / parse_batch, summed over the threads that worked"""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _check(self.dec.L.htj2k_job_host_ms(self.h, ctypes.byref(a), ctypes.byref(b)), "htj2k_job_host_ms")
+        return a.value, b.value
 
     def frame_info(self, f):
         info = Info()

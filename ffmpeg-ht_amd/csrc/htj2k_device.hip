@@ -30,6 +30,41 @@
 
 using namespace htj2k;
 
+/* ------------------------------------------------------------------ k_gather
+ * Puts the byte pool together on the device from the uploaded packets: the host parser only emits the gather table
+ * (J2kSeg, j2k_plan.h) and never touches a code-block byte.  One wavefront per code-block walks the block's pieces in
+ * order; a piece goes from an arbitrary byte offset of the packet to its place in the 16-byte aligned region of the
+ * block -- single bytes up to the first aligned destination dword, then a dword per lane from two aligned source
+ * dwords (v_alignbyte), single bytes at the end -- and a terminated Part-1 segment gets its 0xFF 0xFF.  The pool was
+ * cleared before, so the pads stay zero.  (jpeg2000dec.c:1508-1516 is the host loop this replaces in the reference:
+ * bytestream2_get_bufferu into cblk->data, packet by packet.) */
+__global__ void __launch_bounds__(256) k_gather(const J2kSeg *__restrict__ segs, const uint32_t *__restrict__ first_seg, int ngroups,
+                                                 const uint8_t *__restrict__ pkt, const uint8_t *__restrict__ lit,
+                                                 uint8_t *__restrict__ pool)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= ngroups) return;
+    const uint32_t s1 = first_seg[g + 1];
+    for (uint32_t s = first_seg[g]; s < s1; s++) {
+        const J2kSeg sg = segs[s];
+        const uint8_t *src = ((sg.flags & J2K_SEG_LIT) ? lit : pkt) + sg.src;
+        uint8_t *dst = pool + sg.dst;
+        const uint32_t head = min(sg.len, (uint32_t)(-(intptr_t)dst & 3));
+        if ((uint32_t)lane < head) dst[lane] = src[lane];
+        const uint32_t body = (sg.len - head) >> 2, tail0 = head + 4 * body;
+        const uint8_t *bs = src + head;
+        const uint32_t sh = (uint32_t)((uintptr_t)bs & 3);
+        const uint32_t *al = (const uint32_t *)(bs - sh);
+        uint32_t *out = (uint32_t *)(dst + head);
+        for (uint32_t k = lane; k < body; k += 64) {
+            const uint32_t lo = al[k], hi = sh ? al[k + 1] : 0u;
+            out[k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        }
+        if ((uint32_t)lane < sg.len - tail0) dst[tail0 + lane] = src[tail0 + lane];
+        if ((sg.flags & J2K_SEG_TERM) && lane < 2) dst[sg.len + lane] = 0xFF;
+    }
+}
+
 #define LOG_ERROR 16
 #define LOG_WARNING 24
 #define LOG_INFO 32
@@ -95,6 +130,8 @@ struct htj2k_ctx {
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
     int parse_threads = 0;             /* host threads that parse the frames of a batch; 0 = min(cores, 16) */
+    int device_gather = 1;             /* 1: the packets are uploaded as they are and k_gather puts the byte pool together on the
+                                        * device (the parser does not touch code-block bytes); 0: the parser gathers on the host */
     std::mutex log_mutex;
 };
 
@@ -114,8 +151,10 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
 struct FrameSlot {                     /* one frame of a batch */
     J2kParser *parser = nullptr;
     const J2kPlan *plan = nullptr;
-    std::vector<uint8_t> pkt;          /* private copy: the caller's packet is only borrowed for the call */
-    HostBuf h_bytes;                   /* the parser gathers the codeblock bytes straight into pinned memory */
+    HostBuf h_pkt;                     /* device gather: the packet staged in pinned memory (the caller's is only borrowed for the call) */
+    size_t pkt_base = 0;               /* ... and where it goes in d_pkt */
+    HostBuf h_bytes;                   /* host gather: the parser gathers the codeblock bytes straight into pinned memory */
+    float ms_stage = 0, ms_parse = 0;  /* host time of the last parse_batch: staging copy, parser */
     uint32_t block_base = 0, tc_base = 0, sample_base = 0;
     size_t bytes_base = 0;
     DevBuf d_out[4];
@@ -152,6 +191,13 @@ struct htj2k_job {
     size_t mq_scratch_units = 0;       /* 512-byte row slots of k_mq_decode's scratch */
     uint32_t mq_planes = 1;            /* most bit-planes of a Part-1 block: sizes the LDS of k_mq_decode */
     DevBuf d_mqwaves, d_mqscratch;
+    /* device gather: all packets of the batch, the parsers' literal bytes, the merged gather table, first piece of every block */
+    bool dev_gather = false;
+    DevBuf d_pkt, d_lit, d_gsegs, d_ggroups;
+    std::vector<J2kSeg> gsegs;
+    std::vector<uint32_t> ggroups;
+    std::vector<uint8_t> lit;
+    size_t pkt_bytes = 0;
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
     size_t nrefmasks = 0;
@@ -283,6 +329,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "fuse_pack")) { c->fuse_pack = value ? 1 : 0; return 0; }
     if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "device_gather")) { c->device_gather = value ? 1 : 0; return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
@@ -317,10 +364,12 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     j->d_t0.release(); j->d_t1.release(); j->d_desc.release(); j->d_qsym.release(); j->d_qoff.release();
     j->d_vlcu.release(); j->d_melu.release(); j->d_reflist.release(); j->d_roff.release(); j->d_refbits.release();
     j->d_mqwaves.release(); j->d_mqscratch.release();
+    j->d_pkt.release(); j->d_lit.release(); j->d_gsegs.release(); j->d_ggroups.release();
     for (FrameSlot &f : j->frames) {
         for (int i = 0; i < 4; i++) f.d_out[i].release();
         j2k_parser_free(f.parser);
         f.h_bytes.release();
+        f.h_pkt.release();
     }
     for (int i = 0; i < 6; i++) if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
     for (hipEvent_t e : j->lev_ev) if (e) (void)hipEventDestroy(e);
@@ -381,6 +430,7 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
     if ((int)j->frames.size() < n) j->frames.resize(n);
     j->blocks.clear(); j->tilecomps.clear(); j->tc_frame.clear();
     size_t nbytes = 0, nsamples = 0;
+    j->dev_gather = c->device_gather != 0;
     for (int f = 0; f < n; f++) {
         FrameSlot &F = j->frames[f];
         if (!F.parser) {
@@ -388,10 +438,12 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
             if (!F.parser) return HTJ2K_ERR_ENOMEM;
             j2k_parser_set_log(F.parser, parser_log_tramp, c);
         }
-        /* the codeblock bytes are gathered straight into pinned memory: the H2D copy of the upload
-         * then runs at PCIe rate and truly asynchronously (re-registered on every call: the
-         * FrameSlot may have moved when the vector grew) */
+        /* host gather: the codeblock bytes are gathered straight into pinned memory; device gather: the packet is staged
+         * in pinned memory as it is.  Either way the H2D copy of the upload then runs at PCIe rate and truly asynchronously
+         * (the hook is re-registered on every call: the FrameSlot may have moved when the vector grew) */
         F.h_bytes.device = c->device;
+        F.h_pkt.device = c->device;
+        j2k_parser_set_gather(F.parser, !j->dev_gather);
         j2k_parser_set_bytes_alloc(F.parser, [](void *opaque, size_t nb) -> void * { return ((HostBuf *)opaque)->ensure(nb); },
                                    &F.h_bytes);
         F.plan = nullptr;
@@ -402,11 +454,27 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
         int nthreads = c->parse_threads > 0 ? c->parse_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (nthreads > n) nthreads = n;
         std::atomic<int> next(0);
+        const bool stage = j->dev_gather;
         auto work = [&]() {
             for (;;) {
                 const int f = next.fetch_add(1);
                 if (f >= n) break;
-                rc[f] = j2k_parse(j->frames[f].parser, pkts[f], sizes[f], &c->opts, 0, &j->frames[f].plan);
+                FrameSlot &F = j->frames[f];
+                const uint8_t *src = pkts[f];
+                const auto t0 = std::chrono::steady_clock::now();
+                if (stage) {
+                    const size_t sz = sizes[f] > 0 ? (size_t)sizes[f] : 0;
+                    uint8_t *h = (uint8_t *)F.h_pkt.ensure(sz + 64);
+                    if (!h) { rc[f] = HTJ2K_ERR_ENOMEM; continue; }
+                    memcpy(h, src, sz);
+                    memset(h + sz, 0, 64);
+                    src = h;
+                }
+                const auto t1 = std::chrono::steady_clock::now();
+                rc[f] = j2k_parse(F.parser, src, sizes[f], &c->opts, 0, &F.plan);
+                const auto t2 = std::chrono::steady_clock::now();
+                F.ms_stage = std::chrono::duration<float, std::milli>(t1 - t0).count();
+                F.ms_parse = std::chrono::duration<float, std::milli>(t2 - t1).count();
             }
         };
         if (nthreads <= 1) {
@@ -420,6 +488,8 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
         for (int f = 0; f < n; f++)
             if (rc[f] < 0) return rc[f];                   /* the first failing frame in submission order */
     }
+    j->gsegs.clear(); j->ggroups.clear(); j->lit.clear();
+    size_t pkt_bytes = 0;
     for (int f = 0; f < n; f++) {
         FrameSlot &F = j->frames[f];
         const J2kPlan *pl = F.plan;
@@ -444,9 +514,29 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
             j->tilecomps.push_back(tc);
             j->tc_frame.push_back(f);
         }
+        if (j->dev_gather) {
+            /* the frame's gather table joins the job's: sources re-based to where the packet / the literal bytes will
+             * sit on the device, destinations to the frame's part of the pool */
+            if (pkt_bytes + (size_t)pl->pkt_size > 0xFFFFFF00ull || j->lit.size() + pl->nlit > 0xFFFFFF00ull ||
+                j->gsegs.size() + pl->nsegs > 0xFFFFFF00ull)
+                return HTJ2K_ERR_PATCHWELCOME;
+            F.pkt_base = pkt_bytes;
+            const uint32_t lit_base = (uint32_t)j->lit.size(), seg_base = (uint32_t)j->gsegs.size();
+            for (uint32_t k = 0; k < pl->nsegs; k++) {
+                J2kSeg g = pl->segs[k];
+                g.src += (g.flags & J2K_SEG_LIT) ? lit_base : (uint32_t)pkt_bytes;
+                g.dst += (uint32_t)nbytes;
+                j->gsegs.push_back(g);
+            }
+            for (int i = 0; i < pl->nblocks; i++) j->ggroups.push_back(seg_base + pl->blk_seg0[i]);
+            j->lit.insert(j->lit.end(), pl->lit, pl->lit + pl->nlit);
+            pkt_bytes += ((size_t)pl->pkt_size + 64 + 15) & ~(size_t)15;
+        }
         nbytes += (pl->nbytes + 63) & ~(size_t)63;
         nsamples += pl->nsamples;
     }
+    if (j->dev_gather) j->ggroups.push_back((uint32_t)j->gsegs.size());
+    j->pkt_bytes = pkt_bytes;
     j->nbytes = nbytes;
     j->nsamples = nsamples;
     j->nframes = n;
@@ -462,6 +552,16 @@ extern "C" int htj2k_job_parse(htj2k_ctx *c, const uint8_t *pkt, int size, htj2k
 }
 
 extern "C" int htj2k_job_num_frames(const htj2k_job *j) { return j ? j->nframes : HTJ2K_ERR_EINVAL; }
+
+extern "C" int htj2k_job_host_ms(const htj2k_job *j, float *ms_parse, float *ms_stage)
+{
+    if (!j || j->nframes <= 0) return HTJ2K_ERR_EINVAL;
+    float p = 0, s = 0;
+    for (int f = 0; f < j->nframes; f++) { p += j->frames[f].ms_parse; s += j->frames[f].ms_stage; }
+    if (ms_parse) *ms_parse = p / j->nframes;
+    if (ms_stage) *ms_stage = s / j->nframes;
+    return 0;
+}
 
 extern "C" int htj2k_job_frame_info(const htj2k_job *j, int frame, htj2k_info *info)
 {
@@ -967,11 +1067,35 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     }
     if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
-    for (int f = 0; f < j->nframes; f++) {
-        const FrameSlot &F = j->frames[f];
-        if (F.plan->nbytes)
-            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_bytes.p + F.bytes_base, F.plan->bytes, F.plan->nbytes,
+    if (j->dev_gather) {
+        if ((r = j->d_pkt.ensure(j->pkt_bytes + 256)) < 0 || (r = j->d_lit.ensure(j->lit.size() + 64)) < 0 ||
+            (r = j->d_gsegs.ensure((j->gsegs.size() + 1) * sizeof(J2kSeg))) < 0 ||
+            (r = j->d_ggroups.ensure((j->ggroups.size() + 1) * sizeof(uint32_t))) < 0) return r;
+        for (int f = 0; f < j->nframes; f++) {
+            const FrameSlot &F = j->frames[f];
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_pkt.p + F.pkt_base, F.h_pkt.p, (size_t)F.plan->pkt_size + 64,
                                       hipMemcpyHostToDevice, j->stream));
+        }
+        if (!j->lit.empty())
+            HIP_TRY(c, hipMemcpyAsync(j->d_lit.p, j->lit.data(), j->lit.size(), hipMemcpyHostToDevice, j->stream));
+        if (!j->gsegs.empty())
+            HIP_TRY(c, hipMemcpyAsync(j->d_gsegs.p, j->gsegs.data(), j->gsegs.size() * sizeof(J2kSeg), hipMemcpyHostToDevice, j->stream));
+        HIP_TRY(c, hipMemcpyAsync(j->d_ggroups.p, j->ggroups.data(), j->ggroups.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->stream));
+        HIP_TRY(c, hipMemsetAsync(j->d_bytes.p, 0, j->nbytes + 256, j->stream));
+        const int ngroups = (int)j->ggroups.size() - 1;
+        if (ngroups > 0 && !j->gsegs.empty()) {
+            hipLaunchKernelGGL(k_gather, dim3((ngroups + 3) / 4), dim3(256), 0, j->stream, (const J2kSeg *)j->d_gsegs.p,
+                               (const uint32_t *)j->d_ggroups.p, ngroups, (const uint8_t *)j->d_pkt.p, (const uint8_t *)j->d_lit.p,
+                               (uint8_t *)j->d_bytes.p);
+            HIP_TRY(c, hipGetLastError());
+        }
+    } else {
+        for (int f = 0; f < j->nframes; f++) {
+            const FrameSlot &F = j->frames[f];
+            if (F.plan->nbytes)
+                HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_bytes.p + F.bytes_base, F.plan->bytes, F.plan->nbytes,
+                                          hipMemcpyHostToDevice, j->stream));
+        }
     }
     for (int f = 0; f < j->nframes; f++) {                 /* PAL8: the palette is the second plane (jpeg2000dec.c:2900-2901) */
         const FrameSlot &F = j->frames[f];

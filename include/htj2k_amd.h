@@ -140,6 +140,10 @@ int  htj2k_job_parse(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size, htj2k_job
 int  htj2k_job_parse_batch(htj2k_ctx *ctx, const uint8_t *const *pkts, const int *pkt_sizes, int nframes,
                            htj2k_job **job);
 int  htj2k_job_num_frames(const htj2k_job *job);
+/* host cost of the last htj2k_job_parse(_batch), per frame and per thread that worked on it: `ms_parse` the marker +
+ * Tier-2 parse (no code-block byte is read with "device_gather", the default), `ms_stage` the copy of the packet
+ * into pinned memory that the H2D transfer then starts from */
+int  htj2k_job_host_ms(const htj2k_job *job, float *ms_parse, float *ms_stage);
 int  htj2k_job_frame_info(const htj2k_job *job, int frame, htj2k_info *info);
 int  htj2k_job_download_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
 /* per-launch device time (ms) and algorithmic bytes (2 * 4 * lh * lv per plane and level, one
@@ -222,6 +226,9 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
  *   "ll16"        1 (default): such jobs also hold the LL bands between the IDWT levels as 16-bit samples, with a check
  *                 on the device and a second run with int32 LL bands should one not fit (htj2k_job_ll16)
+ *   "device_gather"  1 (default): packets are uploaded as they are and the byte pool of the job is put together by
+ *                 k_gather on the device from the parser's gather table; 0: the parser copies the code-block bytes
+ *                 into the pool on the host
  *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
  *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);

@@ -764,3 +764,37 @@ def test_c_example_program(orc, tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.count("frame ") == len(names), r.stdout
     assert out.read_bytes() == want
+
+
+def test_device_gather_matches_host_gather_and_the_oracle(dec, orc):
+    """"device_gather" (default): the packets are uploaded as they are and k_gather builds the byte pool from the parser's
+    gather table; 0: the parser copies the code-block bytes on the host.  Same frames either way, and the oracle's --
+    on single- and multi-piece blocks: HT, Part-1 with terminated segments (0xFF 0xFF + trailers), MIXED, quality layers
+    (OpenJPEG fixtures), tile-parts / PPM / PPT variants (tests/cs_rewrite.py), and all of them in one batch."""
+    import cs_rewrite
+    z = np.load(os.path.join(HERE, "golden", "opj_part1.npz"))
+    items = [(n, streams.get(n)[0]) for n in ("gray_l5_cb64", "rgb_tiles_offsets", "gray_3passes", "p1_bypass_termall", "p1_all_switches",
+                                              "p1_rgb_tiles", "mixed_rgb_cb32", "tiny_1x1", "all_zero", "yuv420p8", "placeholder_2_3p")]
+    items += [(k, z[k].tobytes()) for k in z.files if k.endswith(".j2k") and z[k[:-4] + ".lossless"][0]]
+    base = vecgen.encode(streams._img(190, 131, 3, 8, 6), part1=True, cblk_style=0x05, tile=(64, 64), nlevels=3, sop=True, eph=True)
+    items += [("p1_termall_tiles." + n, d) for n, d in cs_rewrite.variants(base, False) if n in ("tp3_tlm_plt", "ppm", "ppt_tp3", "coc_qcc_tile")]
+    base = vecgen.encode(streams._img(190, 131, 3, 8, 5), mct=1, prog=2, prec=[(7, 7), (6, 6)], nlevels=3, sop=True, eph=True, cap_extra_bits=0x1800)
+    items += [("ht_rgb_rpcl." + n, d) for n, d in cs_rewrite.variants(base, True) if n in ("tp_each_packet", "ppt", "ppm", "tp3_interleaved")]
+    dec.set_int("bitexact", 0); dec.set_int("reduction_factor", 0)
+    want = {}
+    for name, data in items:
+        want[name] = orc.decode(data)[1]
+    try:
+        for gather in (1, 0):
+            dec.set_int("device_gather", gather)
+            for name, data in items:
+                info, planes, consumed, st = dec.decode(data)
+                assert all(np.array_equal(a, b) for a, b in zip(planes, want[name])), (name, gather)
+            job = dec.job().parse_batch([d for _, d in items]).upload().run().wait()
+            for f, (name, _) in enumerate(items):
+                assert all(np.array_equal(a, b) for a, b in zip(job.download_frame(f)[1], want[name])), (name, gather, "batch")
+            ms_parse, ms_stage = job.host_ms()
+            assert ms_parse > 0 and (ms_stage > 1e-3) == bool(gather)     # the staging copy exists only with device gather
+            job.free()
+    finally:
+        dec.set_int("device_gather", 1)

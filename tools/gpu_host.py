@@ -8,7 +8,8 @@ streams = bench.make_streams(4, 0)
 pk = [m.packet(x) for x in streams]
 batch = [pk[i % 4] for i in range(8)]
 dec = m.Decoder()
-for thr in (1, 4, 8, 16):
+for gather, thr in ((1, 1), (1, 4), (1, 16), (0, 1), (0, 16)):
+    dec.set_int("device_gather", gather)
     dec.set_int("parse_threads", thr)
     job = dec.job()
     for it in range(3):
@@ -20,6 +21,7 @@ for thr in (1, 4, 8, 16):
         t5 = time.perf_counter()
         for f in range(8): job.download_frame(f) if False else dec.L.htj2k_job_download_frame(dec.h, job.h, f, __import__("ctypes").byref(buf[1]))
         t6 = time.perf_counter()
-    print("threads %2d: parse %.2f ms  upload(call) %.2f  upload(wait) %.2f  run+wait %.2f  d2h(8, pageable) %.2f" % (
-        thr, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t6 - t5) * 1e3), flush=True)
+    hp, hs = job.host_ms()
+    print("device_gather %d threads %2d: parse_batch(8) %.2f ms [per frame and thread: parse %.3f, staging copy %.3f]  upload(call) %.2f  upload(wait) %.2f  run+wait %.2f  d2h(8, pageable) %.2f" % (
+        gather, thr, (t1 - t0) * 1e3, hp, hs, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t6 - t5) * 1e3), flush=True)
     job.free()
