@@ -3,35 +3,43 @@
 (3840x2160 RGB 8-bit, lossless 5/3 + RCT, 64x64 codeblocks, 5 levels), device-resident.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a launcher: the script starts `python -m torch.distributed.run --nproc-per-node N` itself, one rank
+   per GPU; under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE and checks WORLD_SIZE == N.)
 
 A "step" is one pass of the hot path -- HT block decode + dequantisation, inverse DWT, inverse
 RCT + level shift + clip + rgb24 pack (tile_codeblocks() + the tail of jpeg2000_decode_tile(),
 libavcodec/jpeg2000dec.c:2212-2395) -- over one batch of BATCH synthetic 4K frames whose
 compressed codeblock bytes and descriptors are already resident in HBM when the timed region
 starts; decoded frames stay in HBM.  Host marker/Tier-2 parsing and PCIe are outside the
-timed region (their rates are reported as extra fields and in DESIGN.md, never as `value`).
+timed region (their rates are reported as extra fields, never as `value`).  After the timed region
+the first and the last frame of the batch are downloaded and compared with their source images and with
+the oracle's framecrc (`parity_checked`), and no block may have been rejected.
 
 Frames of a stream are independent, so ranks shard them round-robin with no data-path
 collective ("weak" scaling: every rank decodes its own batch per step).
 
 The JSON line also carries
-  roofline      the IDWT kernels (the HBM-bound stage BASELINE.json's north_star names):
-                algorithmic bytes (sum over levels of 2*4*lh*lv per plane) / their
-                launch durations, measured live with HIP events around every IDWT launch of the
-                timed region on the kernels' own stream, against the 8 TB/s HBM3E peak.  The final
-                level runs fused with the inverse MCT + rgb24 store, so it physically writes 1
-                byte per sample where the algorithmic figure counts 4: `achieved_min_hbm_traffic`
-                and `frac_min_hbm_traffic` restate the rate with that launch counted at
-                4*lh*lv read + frame bytes written (what has to cross HBM at the least), and
-                `copy_ceiling` is the float4-copy rate the microarchitecture guide quotes
-  cpu_baseline  the CPU oracle (a single-thread C restatement of the reference decoder:
-                kind "port") timed on this box's host cores on a bounded sample of the same
-                workload -- test infrastructure used here only as the measured baseline.
+  roofline      the IDWT launches of the timed region (the HBM-bound stage BASELINE.json's north_star names), timed
+                live with HIP events on the kernels' own stream:
+                  achieved / frac   bytes that have to cross HBM (what the kernels read and write at the least: 16-bit
+                                    sub-bands and LL bands where the job keeps them so, 1 byte per sample out of the
+                                    final level that is fused with RCT + rgb24 store) / launch time, against 8 TB/s
+                  algorithmic_GBps  SURVEY 8(d)'s figure (4 B read + 4 B written per sample and level) / launch time --
+                                    a rate for comparison with the CPU figures, not a fraction of the bus
+                  traffic           HBM bytes per launch from the PMC passes committed under profiles/
+  cpu_baseline           the CPU oracle (single-thread C restatement of the reference decoder incl. its host parsing:
+                         kind "port") on a bounded sample of the same frames
+  cpu_baseline_hot_path  the same without host parsing: block decode + IDWT + MCT/write only -- like for like with `value`
+  cpu_baseline_all_cores frame-parallel oracle decodes on all host cores (the reference's frame threads,
+                         libavcodec/pthread_frame.c:856-889)
+  stream240     BASELINE configs[4] end to end: 240 distinct 4K 10-bit RGB frames, packets in host memory -> rgb48
+                frames in page-locked host memory through the asynchronous pipeline, sharded round-robin over the
+                ranks; host parsing and PCIe included (never `value`)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -48,7 +56,8 @@ COPY_CEILING_GBS = 6290.0      # same guide, line 36: float4 copy, 79 % of the s
 def committed_traffic(frames_per_step):
     """HBM bytes per IDWT launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     process): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the IDWT launches of one step of this same
-    workload (tools/prof_r01.sh + tools/make_profiles.py); None when the batch differs from the profiled one."""
+    workload (tools/prof_r02.sh + tools/make_profiles.py); None when the batch differs from the profiled one.
+    The newest matching file wins."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
@@ -79,18 +88,42 @@ def max_over_ranks(seconds):
     return float(t.item())
 
 
-def make_streams(nstreams, rank):
+def make_streams(nstreams, rank, with_images=False):
     """distinct synthetic 4K RGB frames (BASELINE.md section 3 generator) -> HTJ2K codestreams"""
     import vecgen
-    out = []
+    out, imgs = [], []
     for i in range(nstreams):
         img = vecgen.synth_image(WIDTH, HEIGHT, NCOMP, depth=8, seed=2 + i + 16 * rank, noise=8)
         out.append(vecgen.encode(img, mct=1, nlevels=NLEVELS, cb=CB, transform=1))
-    return out
+        imgs.append(img)
+    return (out, imgs) if with_images else out
 
 
-def cpu_baseline(streams, budget_s=12.0):
-    """single-thread CPU oracle on a bounded sample of the same frames"""
+def host_cores():
+    """cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one
+    (a GPU box gives a job a share of the host, not the whole machine)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    try:                                                   # this pool's boxes give a job 16 host cores per GPU
+        import torch
+        n = min(n, 16 * max(1, torch.cuda.device_count()))
+    except Exception:                                      # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baselines(streams, budget_s=10.0):
+    """the CPU oracle on a bounded sample of the bench's frames, on this box's host cores: whole decodes on one
+    thread, the hot path alone (host parsing excluded) on one thread, whole decodes on all cores"""
+    import threading
     import oracle
     orc = oracle.OracleDecoder()
     orc.decode(streams[0])                      # warm caches / page in
@@ -101,10 +134,46 @@ def cpu_baseline(streams, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
+    one = {"value": round(n * WIDTH * HEIGHT / el / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+           "sample": "%d decodes of the bench's 4K RGB lossless frames in %.1f s, single thread, "
+                     "oracle/ (C restatement of the reference decoder incl. its host parsing)" % (n, el)}
+    # hot path only: parse outside the clock, then blocks + IDWT + MCT/write_frame
+    n2, hot, t_parse = 0, 0.0, 0.0
+    while hot < budget_s * 0.6 and n2 < 32:
+        t0 = time.perf_counter()
+        orc.parse(streams[n2 % len(streams)])
+        t1 = time.perf_counter()
+        orc.decode_parsed()
+        orc.idwt()
+        orc.write()
+        hot += time.perf_counter() - t1
+        t_parse += t1 - t0
+        n2 += 1
+    hot_path = {"value": round(n2 * WIDTH * HEIGHT / hot / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+                "sample": "%d frames in %.1f s: tile_codeblocks() (HT block decode + dequantisation + IDWT) + mct_decode + "
+                          "write_frame of the oracle, host parsing (%.1f ms per frame) not counted -- the stages `value` times"
+                          % (n2, hot, t_parse / max(n2, 1) * 1e3)}
     orc.close()
-    return {"value": round(n * WIDTH * HEIGHT / el / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-            "sample": "%d decodes of the bench's 4K RGB lossless frames in %.1f s, single thread, "
-                      "oracle/j2k_oracle.c (C restatement of the reference decoder incl. host parsing)" % (n, el)}
+    # all cores: one oracle decoder per thread (ctypes releases the GIL inside the library), frames handed out round-robin
+    cores = host_cores()
+    counts, stop_at = [0] * cores, time.perf_counter() + budget_s * 0.8
+
+    def worker(k):
+        d = oracle.OracleDecoder()
+        i = k
+        while time.perf_counter() < stop_at:
+            d.decode(streams[i % len(streams)])
+            counts[k] += 1
+            i += cores
+        d.close()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    for t in th: t.start()
+    for t in th: t.join()
+    el = time.perf_counter() - t0
+    allc = {"value": round(sum(counts) * WIDTH * HEIGHT / el / 1e6, 3), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "sample": "%d whole decodes in %.1f s on %d threads, one frame per thread at a time (frame threading)" % (sum(counts), el, cores)}
+    return one, hot_path, allc
 
 
 def two_jobs_leg(dec, packets, steps):
@@ -173,6 +242,70 @@ def part1_leg(dec, nframes, with_cpu):
     return out
 
 
+def stream240_leg(dec, m, rank, world, nframes, barrier):
+    """BASELINE configs[4]: a stream of `nframes` distinct 4K 10-bit lossless RGB frames (-> rgb48, samples << 6), frame
+    i on rank i mod world, every rank's share through the asynchronous pipeline: packets in pageable host memory ->
+    frames in page-locked host memory.  Host parsing, staging, PCIe both ways and the kernels are all inside the clock.
+    Returns (seconds on this rank, frames of this rank, parity)."""
+    import concurrent.futures
+    import numpy as np
+    import vecgen
+    mine = shard_frames(nframes, rank, world)
+    workers = max(1, min(16, host_cores() // max(world, 1)))
+
+    def make(i):                                           # ctypes releases the GIL inside the encoder
+        img = vecgen.synth_image(WIDTH, HEIGHT, NCOMP, depth=10, seed=1000 + i, noise=20)
+        data = vecgen.encode(img, depth=10, mct=1, nlevels=NLEVELS, cb=CB)
+        return data, (img if i in (mine[0], mine[-1]) else None)
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+        made = list(ex.map(make, mine))
+    t_enc = time.perf_counter() - t0
+    keep = {mine[k]: im for k, (_, im) in enumerate(made) if im is not None}
+    nbytes = sum(len(d) for d, _ in made)
+    info0 = dec.probe(made[0][0])
+    pkts = [m.packet(d) for d, _ in made]                  # padded buffers, sent by reference (htj2k_pipe_send_ref)
+    del made
+    pinned, ptrs = dec.alloc_frame_pinned(info0)
+    first = last = None
+    pipe = dec.pipe(batch=8, depth=3)
+    # warm-up outside the clock: buffers of all jobs get allocated
+    warm = min(24, len(pkts))
+    sent = got = 0
+    while got < warm:
+        while sent < warm and pipe.send(pkts[sent]):
+            sent += 1
+        if sent == warm:
+            pipe.flush()
+        pipe.receive(into=pinned)
+        got += 1
+    barrier()
+    t0 = time.perf_counter()
+    sent = got = 0
+    while got < len(pkts):
+        while sent < len(pkts) and pipe.send(pkts[sent]):
+            sent += 1
+        if sent == len(pkts):
+            pipe.flush()
+        if pipe.receive(into=pinned) is None:
+            break
+        if got == 0:
+            first = pinned[0][0].copy()
+        if got == len(pkts) - 1:
+            last = pinned[0][0].copy()
+        got += 1
+    dt = time.perf_counter() - t0
+    barrier()
+    pipe.close()
+    ok = got == len(pkts)
+    for fr, idx in ((first, mine[0]), (last, mine[-1])):
+        img = keep.get(idx)
+        ok = ok and fr is not None and img is not None and \
+            np.array_equal(fr.view(np.uint16).reshape(HEIGHT, WIDTH, 3) >> 6, np.stack(img, -1))
+    dec.free_frame_pinned(ptrs)
+    return dt, len(pkts), ok, t_enc, nbytes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,13 +319,26 @@ def main():
     ap.add_argument("--part1", type=int, default=0, metavar="FRAMES",
                     help="also time the same 4K frames coded with Part-1 (MQ) blocks: FRAMES per step through k_mq_decode "
                          "(rank 0, reported as the extra object \"part1\"; SURVEY 8f rank 3, not part of `value`)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the three single-frame htj2k_decode() calls after the "
-                    "timed region (profiling runs: every kernel launch in the trace is then a batch launch)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-side legs after the timed region (profiling runs: "
+                    "every kernel launch in the trace is then a batch launch)")
+    ap.add_argument("--stream240", type=int, default=240, metavar="FRAMES",
+                    help="frames of the configs[4] end-to-end leg (all ranks; 0 = skip; skipped with --no-e2e)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing has touched the GPU yet (not even `import torch`), the ranks are children
+        # of this process and its exit status is theirs.
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU" % (args.gpus, world))
+    import numpy as np
     import torch
     # rehearsal knobs (never set by the driver): several ranks on the one GPU of a test box, over gloo
     backend = os.environ.get("HTJ2K_BENCH_BACKEND", "nccl")
@@ -202,19 +348,21 @@ def main():
         torch.cuda.set_device(device)
         dist.init_process_group(backend)
     import ffmpeg_ht_amd as m
+    import oracle
 
-    streams = make_streams(min(args.distinct, args.batch), rank)
+    streams, images = make_streams(min(args.distinct, args.batch), rank, with_images=True)
     batch = [streams[i % len(streams)] for i in range(args.batch)]
     njobs = max(1, min(args.jobs, args.batch))
     per_job = [batch[i::njobs] for i in range(njobs)]
 
     dec = m.Decoder(device_id=device)
     per_job = [[m.packet(x) for x in b] for b in per_job]     # padded packet buffers, built once
-    jobs = [dec.job().parse_batch(b) for b in per_job]         # cold: allocates the pinned byte pools
+    jobs = [dec.job().parse_batch(b) for b in per_job]         # cold: allocates the pinned staging buffers
     t0 = time.perf_counter()
     for job, b in zip(jobs, per_job):
         job.parse_batch(b)
     t_parse = time.perf_counter() - t0
+    host_ms = [job.host_ms() for job in jobs]
     for job in jobs:                                       # cold: allocates the device buffers
         job.upload()
     for job in jobs:
@@ -239,7 +387,6 @@ def main():
             job.run(7)
     for job in jobs:
         job.wait()
-    # parity spot-check of what is being timed: frame 0 of the batch is lossless vs its source
     barrier()
     t0 = time.perf_counter()
     ht_ms = idwt_ms = pack_ms = 0.0
@@ -267,6 +414,24 @@ def main():
     frames_total = args.steps * args.batch * world
     value = frames_total * WIDTH * HEIGHT / elapsed / 1e6
 
+    # parity of what was timed: the first and the last frame of the batch, as the last timed step left them in HBM,
+    # against their source images (the streams are lossless) and against the oracle's framecrc; no block rejected
+    parity = True
+    block_errors = sum(job.block_errors() for job in jobs)
+    orc = oracle.OracleDecoder()
+    crc_of_stream = {}
+    for jix, fix in ((0, 0), (njobs - 1, len(per_job[-1]) - 1)):
+        k = (fix * njobs + jix) % len(streams)              # which distinct stream that frame is
+        _, planes = jobs[jix].download_frame(fix)
+        got = planes[0].reshape(HEIGHT, WIDTH, NCOMP)
+        if k not in crc_of_stream:
+            crc_of_stream[k] = oracle.framecrc(orc.decode(streams[k])[1])
+        parity = parity and bool(np.array_equal(got, np.stack(images[k], -1))) and oracle.framecrc(planes) == crc_of_stream[k]
+    orc.close()
+    parity = parity and block_errors == 0
+    if not parity:
+        sys.exit("bench.py: the timed frames do not match their sources / the oracle (block errors: %d)" % block_errors)
+
     # (before the host legs create and destroy their streams: the two jobs' streams should sit on hardware queues of their own)
     two_jobs = None
     if njobs == 1 and not args.no_e2e and world == 1 and args.batch >= 2:
@@ -289,9 +454,9 @@ def main():
     pipe_rate = pipe_rate_pinned = pipe_rate_device = 0.0
     if not args.no_e2e and rank == 0 and world == 1:
         info0 = dec.probe(streams[0])
-        pk = [m.packet(x) for x in streams]
+        pk = [m.packet(x) for x in streams]                # zero-copy sends (htj2k_pipe_send_ref): the staging copy is the workers'
 
-        def run_pipe(buf, nwarm=24, nfr=96):
+        def run_pipe(receive, nwarm=24, nfr=96):
             pipe = dec.pipe(batch=8, depth=3)
             sent = got = 0
             t0 = None
@@ -300,42 +465,44 @@ def main():
                     sent += 1
                 if sent == nwarm + nfr:
                     pipe.flush()
-                if pipe.receive(into=buf) is None:
+                if receive(pipe) is None:
                     break
                 got += 1
                 if got == nwarm:
-                    t0 = time.perf_counter()               # buffers of all three jobs are allocated by now
+                    t0 = time.perf_counter()               # buffers of all jobs are allocated by now
             rate = (got - nwarm) * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6 if t0 and got > nwarm else 0.0
             pipe.close()
             return rate
-        def run_pipe_device(nwarm=24, nfr=192):
-            pipe = dec.pipe(batch=8, depth=3)
-            sent = got = 0
-            t0 = None
-            while got < nwarm + nfr:
-                while sent < nwarm + nfr and pipe.send(pk[sent % len(pk)]):
-                    sent += 1
-                if sent == nwarm + nfr:
-                    pipe.flush()
-                if pipe.receive_device() is None:
-                    break
-                got += 1
-                if got == nwarm:
-                    t0 = time.perf_counter()
-            rate = (got - nwarm) * WIDTH * HEIGHT / (time.perf_counter() - t0) / 1e6 if t0 and got > nwarm else 0.0
-            pipe.close()
-            return rate
-        pipe_rate_device = run_pipe_device()
-        pipe_rate = run_pipe(m.alloc_frame(info0))
+        pipe_rate_device = run_pipe(lambda p: p.receive_device(), nfr=192)
+        buf = m.alloc_frame(info0)
+        pipe_rate = run_pipe(lambda p: p.receive(into=buf))
         pinned, ptrs = dec.alloc_frame_pinned(info0)
-        pipe_rate_pinned = run_pipe(pinned)
+        pipe_rate_pinned = run_pipe(lambda p: p.receive(into=pinned))
         del pinned
         dec.free_frame_pinned(ptrs)
 
+    # BASELINE configs[4], end to end, on every rank
+    stream240 = None
+    if args.stream240 > 0 and not args.no_e2e:
+        n240 = max(args.stream240, world)
+        dt, mine, ok, t_enc, nbytes = stream240_leg(dec, m, rank, world, n240, barrier)
+        dt_all = max_over_ranks(dt)
+        if not ok:
+            sys.exit("bench.py: stream240 frames do not match their sources")
+        stream240 = {"value": round(n240 * WIDTH * HEIGHT / dt_all / 1e6, 1), "unit": "Mpixel/s", "frames": n240,
+                     "frames_this_rank": mine, "seconds": round(dt_all, 4), "parity_checked": True,
+                     "workload": "configs[4]: %d distinct 3840x2160 10-bit RGB lossless 5/3 + RCT frames (rgb48 out), frame i on "
+                                 "rank i mod %d; pageable packets in -> page-locked frames out through htj2k_pipe (batches of 8, "
+                                 "3 in flight); host parsing + staging + PCIe + kernels inside the clock, max over ranks"
+                                 % (n240, world),
+                     "compressed_MB_per_frame": round(nbytes / max(mine, 1) / 1e6, 2),
+                     "encode_s_outside_the_clock": round(t_enc, 1)}
+
     if rank == 0:
-        achieved = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
-        achieved_hbm = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
+        algorithmic = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
+        achieved = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
         traffic = committed_traffic(args.batch) if njobs == 1 else None
+        c16, ll16 = bool(jobs[0].coef16()), jobs[0].ll16() == 1
         res = {
             "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3) at 1/2/4/8 GPU; IDWT HBM GB/s vs peak",
             "value": round(value, 2),
@@ -349,50 +516,67 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            "parity_checked": True,
             "config": {"workload": "configs[1]: 3840x2160 RGB 8-bit lossless 5/3 + RCT, 64x64 codeblocks, 5 levels, "
                                    "single tile, HT cleanup pass only; %d frames per step per GPU in %d concurrent "
                                    "jobs (HIP streams), device-resident input (codeblock bytes + descriptors) and "
                                    "output (rgb24)" % (args.batch, njobs),
                        "frames_per_step": args.batch, "jobs": njobs, "codeblocks_per_step": nblocks,
+                       "distinct_frames": len(streams), "block_errors": block_errors,
                        "sharding": "frames round-robin over ranks, no collective"},
             "roofline": {"bound": "hbm",
-                         "kernel": "k_idwt_stream<5/3> (levels 1-4) + k_idwt_stream_pack<5/3,3> (level 5 fused with RCT + rgb24 store)",
+                         "kernel": "k_idwt_stream_ll16 (levels 1-4: 16-bit sub-bands and LL bands) + k_idwt_stream_pack<5/3, 3> "
+                                   "(level 5 fused with RCT + rgb24 store)" if ll16 else
+                                   "k_idwt_stream<5/3> (levels 1-4) + k_idwt_stream_pack<5/3, 3> (level 5 fused with RCT + rgb24 store)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
                          "launches": nlaunch, "avg_launch_us": round(idwt_launch_ms / max(nlaunch, 1) * 1e3, 2),
+                         "hbm_MB_per_launch": round(idwt_launch_hbm / max(nlaunch, 1) / 1e6, 3),
+                         "algorithmic_GBps": round(algorithmic, 1),
                          "algorithmic_MB_per_launch": round(idwt_launch_bytes / max(nlaunch, 1) / 1e6, 3),
-                         "achieved_min_hbm_traffic": round(achieved_hbm, 1),
-                         "frac_min_hbm_traffic": round(achieved_hbm / HBM_PEAK_GBS, 4),
-                         "min_hbm_MB_per_launch": round(idwt_launch_hbm / max(nlaunch, 1) / 1e6, 3),
                          "copy_ceiling": COPY_CEILING_GBS,
-                         "sub_bands_16bit": bool(jobs[0].coef16()),
-                         "ll_bands_16bit": jobs[0].ll16() == 1,
-                         "note": "achieved/frac count SURVEY 8(d)'s algorithmic bytes (4 B per sample read and written "
-                                 "per level); when sub_bands_16bit is true the sub-bands really move as 2 B samples (exact "
-                                 "for this workload: every band has M_b <= 15), with ll_bands_16bit the LL bands between the "
-                                 "levels too (checked on the device, second run with int32 if one does not fit), so frac can "
-                                 "exceed the share of the bus that is busy -- *_min_hbm_traffic and `traffic` count the "
-                                 "bytes that really move"},
+                         "sub_bands_16bit": c16, "ll_bands_16bit": ll16,
+                         "note": "achieved / frac count the bytes the launches have to move through HBM (per sample: sub-bands "
+                                 "read as 2 B where sub_bands_16bit, LL bands read and written as 2 B where ll_bands_16bit -- "
+                                 "checked on the device, the transform runs again with int32 if one does not fit -- 4 B otherwise; "
+                                 "the final level writes the rgb24 frame, 1 B per sample); algorithmic_GBps is SURVEY 8(d)'s "
+                                 "4 B + 4 B per sample and level over the same time: a rate, not a share of the bus; `traffic` "
+                                 "is what the PMC counters saw per launch"},
             "stage_ms_per_step_sum_over_jobs": {"ht_decode_dequant": round(ht_ms / args.steps, 4),
                                                 "idwt": round(idwt_ms / args.steps, 4),
                                                 "mct_pack": round(pack_ms / args.steps, 4)},
-            "host": {"parse_ms_per_frame": round(t_parse / args.batch * 1e3, 3),
+            "host": {"parse_ms_per_frame_one_core": round(sum(h[0] for h in host_ms) / len(host_ms), 3),
+                     "staging_copy_ms_per_frame_one_core": round(sum(h[1] for h in host_ms) / len(host_ms), 3),
+                     "parse_batch_wall_ms_per_frame": round(t_parse / args.batch * 1e3, 3),
                      "upload_ms_per_frame": round(t_upload / args.batch * 1e3, 3),
                      "end_to_end_Mpixel_s_single_frame_calls": round(e2e, 1),
                      "end_to_end_Mpixel_s_pipeline": round(pipe_rate, 1),
                      "end_to_end_Mpixel_s_pipeline_pinned_frames": round(pipe_rate_pinned, 1),
                      "packets_to_device_frames_Mpixel_s_pipeline": round(pipe_rate_device, 1),
                      "pipeline": "htj2k_pipe: 96 frames after 24 warm-up, batches of 8, 3 in flight, pageable packets in, "
-                                 "frames out into pageable / page-locked (htj2k_host_alloc) planes"},
+                                 "frames out into pageable / page-locked (htj2k_host_alloc) planes",
+                     "note": "parse = marker + Tier-2 parse of one frame on one core (no code-block byte is read: the "
+                             "packets are uploaded as they are and k_gather builds the byte pool on the device); "
+                             "staging copy = the packet's copy into page-locked memory"},
         }
-        if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 run only
-            res["cpu_baseline"] = cpu_baseline(streams)
+        if not args.no_cpu_baseline and world == 1:          # reported baselines of the N = 1 run only
+            one, hot, allc = cpu_baselines(streams)
+            res["cpu_baseline"] = one
+            res["cpu_baseline_hot_path"] = hot
+            res["cpu_baseline_all_cores"] = allc
+            res["speedup"] = {"device_resident_vs_hot_path_1_core": round(value / hot["value"], 1),
+                              "pipeline_vs_whole_decode_1_core": round(pipe_rate_pinned / one["value"], 1) if pipe_rate_pinned else None,
+                              "pipeline_vs_whole_decode_all_cores": round(pipe_rate_pinned / allc["value"], 2) if pipe_rate_pinned else None,
+                              "note": "like with like: `value` (device-resident stages) against the oracle's same stages; the "
+                                      "packets-to-frames pipeline against whole oracle decodes"}
         if args.part1 > 0:
             res["part1"] = part1_leg(dec, args.part1, not args.no_cpu_baseline)
         if two_jobs:
             res["two_jobs"] = two_jobs
+        if stream240:
+            res["stream240"] = stream240
         print(json.dumps(res), flush=True)
     for job in jobs:
         job.free()

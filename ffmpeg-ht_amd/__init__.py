@@ -75,11 +75,11 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
            "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
-           "htj2k_job_parse_batch", "htj2k_job_num_frames", "htj2k_job_host_ms", "htj2k_job_frame_info", "htj2k_job_download_frame",
+           "htj2k_job_parse_batch", "htj2k_job_parse_batch_ex", "htj2k_job_num_frames", "htj2k_job_host_ms", "htj2k_job_frame_info", "htj2k_job_download_frame",
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
-           "htj2k_pipe_receive_device", "htj2k_job_device_frame",
+           "htj2k_pipe_receive_device", "htj2k_job_device_frame", "htj2k_device_to_host",
            "htj2k_splitter_open", "htj2k_splitter_find_end", "htj2k_splitter_parse", "htj2k_splitter_close",
            "htj2k_mxf_next_essence"]
 
@@ -424,6 +424,17 @@ class Decoder:
 
     def pipe(self, batch=8, depth=3):
         return Pipe(self, batch, depth)
+
+    def fetch_device_frame(self, info, fr):
+        """[plane arrays] of a frame whose data[] are device pointers (Pipe.receive_device, Job.device_frame)"""
+        planes = []
+        for p in range(info.nplanes):
+            ls = fr.linesize[p]
+            a = np.zeros((info.plane_height[p], ls), dtype=np.uint8)
+            _check(self.L.htj2k_device_to_host(self.h, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(fr.data[p]),
+                                               ctypes.c_size_t(a.nbytes)), "htj2k_device_to_host")
+            planes.append(a)
+        return planes_to_arrays(info, planes)
 
     def alloc_frame_pinned(self, info):
         """frame planes in page-locked host memory (htj2k_host_alloc); free with free_frame_pinned"""

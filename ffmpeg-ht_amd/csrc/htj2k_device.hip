@@ -152,6 +152,7 @@ struct FrameSlot {                     /* one frame of a batch */
     J2kParser *parser = nullptr;
     const J2kPlan *plan = nullptr;
     HostBuf h_pkt;                     /* device gather: the packet staged in pinned memory (the caller's is only borrowed for the call) */
+    const uint8_t *h2d_src = nullptr;  /* ... or the caller's packet itself when that is page-locked (htj2k_job_parse_batch_ex) */
     size_t pkt_base = 0;               /* ... and where it goes in d_pkt */
     HostBuf h_bytes;                   /* host gather: the parser gathers the codeblock bytes straight into pinned memory */
     float ms_stage = 0, ms_parse = 0;  /* host time of the last parse_batch: staging copy, parser */
@@ -355,6 +356,14 @@ extern "C" void htj2k_host_free(htj2k_ctx *c, void *ptr)
     if (ptr) (void)hipHostFree(ptr);
 }
 
+extern "C" int htj2k_device_to_host(htj2k_ctx *c, void *dst, const void *src, size_t size)
+{
+    if (!c || !dst || !src) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(dst, src, size, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
 {
     (void)c;
@@ -417,6 +426,12 @@ static int job_new(htj2k_ctx *c, htj2k_job **out)
  * longer codeblock table, more planes per IDWT level, more tiles to pack. */
 extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, const int *sizes, int n, htj2k_job **job)
 {
+    return htj2k_job_parse_batch_ex(c, pkts, sizes, n, nullptr, job);
+}
+
+extern "C" int htj2k_job_parse_batch_ex(htj2k_ctx *c, const uint8_t *const *pkts, const int *sizes, int n, const uint8_t *pinned,
+                                        htj2k_job **job)
+{
     if (!c || !pkts || !sizes || n <= 0 || !job) return HTJ2K_ERR_EINVAL;
     if (!*job) {
         int r = job_new(c, job);
@@ -462,13 +477,17 @@ extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, c
                 FrameSlot &F = j->frames[f];
                 const uint8_t *src = pkts[f];
                 const auto t0 = std::chrono::steady_clock::now();
-                if (stage) {
+                F.h2d_src = nullptr;
+                if (stage && pinned && pinned[f]) {
+                    F.h2d_src = src;                        /* page-locked and stable: the upload reads the packet itself */
+                } else if (stage) {
                     const size_t sz = sizes[f] > 0 ? (size_t)sizes[f] : 0;
                     uint8_t *h = (uint8_t *)F.h_pkt.ensure(sz + 64);
                     if (!h) { rc[f] = HTJ2K_ERR_ENOMEM; continue; }
                     memcpy(h, src, sz);
                     memset(h + sz, 0, 64);
                     src = h;
+                    F.h2d_src = h;
                 }
                 const auto t1 = std::chrono::steady_clock::now();
                 rc[f] = j2k_parse(F.parser, src, sizes[f], &c->opts, 0, &F.plan);
@@ -1073,7 +1092,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             (r = j->d_ggroups.ensure((j->ggroups.size() + 1) * sizeof(uint32_t))) < 0) return r;
         for (int f = 0; f < j->nframes; f++) {
             const FrameSlot &F = j->frames[f];
-            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_pkt.p + F.pkt_base, F.h_pkt.p, (size_t)F.plan->pkt_size + 64,
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_pkt.p + F.pkt_base, F.h2d_src, (size_t)F.plan->pkt_size + 64,
                                       hipMemcpyHostToDevice, j->stream));
         }
         if (!j->lit.empty())
@@ -1490,6 +1509,7 @@ extern "C" int htj2k_job_read_plane(htj2k_ctx *c, htj2k_job *j, int tc, void *ds
     if (dst_bytes < n) return HTJ2K_ERR_EINVAL;
     const int fb = j->final_eff.empty() ? 0 : j->final_eff[tc];
     if (j->fused_last && !j->plane_fused.empty() && j->plane_fused[tc]) return HTJ2K_ERR_EINVAL;   /* never materialised */
+    if (!j->ll16_checked) { const int r = job_settle(c, j); if (r < 0) return r; }
     HIP_TRY(c, hipStreamSynchronize(j->stream));
     HIP_TRY(c, hipMemcpy(dst, buf_ptr(j, fb) + t.plane_off, n, hipMemcpyDeviceToHost));
     return 0;
@@ -1524,6 +1544,9 @@ extern "C" int htj2k_job_download(htj2k_ctx *c, htj2k_job *j, htj2k_frame *frame
 extern "C" int htj2k_job_device_frame(htj2k_ctx *c, htj2k_job *j, int f, htj2k_frame *frame)
 {
     if (!c || !j || f < 0 || f >= j->nframes || !frame) return HTJ2K_ERR_EINVAL;
+    /* the planes are final only once the 16-bit LL check of the last run has been looked at (and the transform run
+     * again if it tripped): that also waits for the job's stream */
+    if (!j->ll16_checked) { const int r = job_settle(c, j); if (r < 0) return r; }
     const FrameSlot &F = j->frames[f];
     const J2kPlan *pl = F.plan;
     memset(frame, 0, sizeof(*frame));
@@ -1537,7 +1560,8 @@ extern "C" int htj2k_job_device_frame(htj2k_ctx *c, htj2k_job *j, int f, htj2k_f
     return 0;
 }
 
-/* device address of an output plane of frame 0 (for callers that keep frames on the GPU) */
+/* device address of an output plane of frame 0 (for callers that keep frames on the GPU); htj2k_job_wait must have
+ * returned since the last run: only then are the planes final (this call has no context to wait with) */
 extern "C" void *htj2k_job_device_plane(htj2k_job *j, int plane, int *linesize)
 {
     if (!j || j->nframes <= 0 || plane < 0 || plane > 3) return nullptr;
@@ -1784,6 +1808,18 @@ extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int 
  * a sample buffer (unit parity against ff_jpeg2000_decode_htj2k + dequantisation) */
 /* decode_cblk() + dequantisation on a caller-built table of Part-1 blocks: every descriptor carries J2K_BLK_PART1 and
  * its bytes are laid out as j2k_parse.c does it (j2k_plan.h: segments, 0xFF 0xFF terminators, J2kPart1Trailer) */
+/* A caller-built descriptor (the unit entry points below) gets the guarantees the job path has from the host parser:
+ * the block is at most 4096 samples and 1024 in either direction (jpeg2000htdec.c:1230-1232, what the kernels' LDS and
+ * quad-symbol sizing assume), its window lies inside the coefficient buffer, the numbers the kernels shift by are in
+ * range. */
+static bool block_desc_ok(const J2kBlock &b, size_t nsamples)
+{
+    if (!b.w || !b.h || b.w > 1024 || b.h > 1024 || (uint32_t)b.w * b.h > 4096 || b.stride < b.w) return false;
+    if ((size_t)b.plane_off + (size_t)(b.h - 1) * b.stride + b.w > nsamples) return false;
+    if (b.roi_shift > 30 || b.npasses >= 100) return false;
+    return true;
+}
+
 extern "C" int htj2k_mq_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks, const uint8_t *bytes_in, size_t nbytes_in,
                                void *coef, size_t nsamples, int *status)
 {
@@ -1793,9 +1829,15 @@ extern "C" int htj2k_mq_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     std::vector<uint8_t> pool(16, 0);
     for (int i = 0; i < nblocks; i++) {
         J2kBlock &b = blk[i];
-        if (!(b.flags & J2K_BLK_PART1)) return HTJ2K_ERR_EINVAL;
+        if (!(b.flags & J2K_BLK_PART1) || !block_desc_ok(b, nsamples) || b.M_b > 37) return HTJ2K_ERR_EINVAL;
         const size_t len = J2K_P1_TRAILER_OFF(b.lcup) + 4 + 2 * (size_t)b.lref;
         if ((size_t)b.data_off + len > nbytes_in) return HTJ2K_ERR_EINVAL;
+        {   /* the trailer is trusted by the kernel: segment count and starts must lie inside the block's bytes */
+            const J2kPart1Trailer *tr = (const J2kPart1Trailer *)(bytes_in + b.data_off + J2K_P1_TRAILER_OFF(b.lcup));
+            if (tr->nterm != b.lref || tr->bandpos > 3) return HTJ2K_ERR_EINVAL;
+            for (uint32_t k = 0; k < tr->nterm; k++)
+                if (tr->start[k] > b.lcup) return HTJ2K_ERR_EINVAL;
+        }
         const size_t o = pool.size();
         pool.resize(o + J2K_P1_REGION(b.lcup, b.lref), 0);
         memcpy(pool.data() + o, bytes_in + b.data_off, len);
@@ -1863,6 +1905,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     for (int i = 0; i < nblocks; i++) {
         J2kBlock &b = blk[i];
         const size_t len = (size_t)b.lcup + b.lref;
+        if ((b.flags & J2K_BLK_PART1) || !block_desc_ok(b, nsamples) || b.M_b > 30) return HTJ2K_ERR_EINVAL;
         if ((size_t)b.data_off + len > nbytes_in) return HTJ2K_ERR_EINVAL;
         const size_t o = pool.size();
         pool.resize(o + J2K_BLOCK_REGION(len), 0);

@@ -27,20 +27,17 @@ namespace {
 
 constexpr int PIPE_PAD = 64;           /* AV_INPUT_BUFFER_PADDING_SIZE: the private packet copies carry it */
 
-enum SlotState { SLOT_FREE, SLOT_FILLING, SLOT_RUNNING, SLOT_DONE };
+enum SlotState { SLOT_FREE, SLOT_FILLING, SLOT_RUNNING, SLOT_DONE,
+                 SLOT_HELD };          /* all frames handed out as device pointers: the job may not be reused yet */
 
-struct Packet {                        /* either a private copy or a reference the caller keeps alive */
+struct PinBuf { uint8_t *p = nullptr; size_t cap = 0; };   /* page-locked packet memory (htj2k_host_alloc), recycled */
+
+struct Packet {                        /* either a private copy (in page-locked memory) or a reference the caller keeps alive */
     const uint8_t *data = nullptr;
     int size = 0;
-    uint8_t *own = nullptr;
+    PinBuf own;
     void (*release)(void *) = nullptr;
     void *opaque = nullptr;
-    void drop()
-    {
-        if (release) release(opaque);
-        delete[] own;
-        data = nullptr; own = nullptr; release = nullptr; size = 0;
-    }
 };
 
 struct Slot {
@@ -49,6 +46,10 @@ struct Slot {
     SlotState state = SLOT_FREE;
     int rc = 0;                        /* result of the batch run */
     int next_out = 0;                  /* next frame of the batch to hand out */
+    bool device_handout = false;       /* some frame of the batch left as device pointers */
+    long release_at = 0;               /* SLOT_HELD: free again once this many batches have been handed out in full */
+    std::vector<htj2k_job *> retry;    /* failed batch, device hand-out: one single-frame job per frame (the pointers stay valid
+                                        * as long as the slot's) */
     std::thread worker;
 };
 
@@ -62,14 +63,26 @@ struct htj2k_pipe {
     std::mutex m;
     std::condition_variable cv;
     htj2k_job *single = nullptr;       /* per-frame retry of a failed batch */
+    std::vector<PinBuf> spare;         /* packet buffers waiting for re-use */
+    long batches_out = 0;              /* batches whose frames have all been handed out */
 };
+
+/* caller holds the lock */
+static void drop_packet(htj2k_pipe *p, Packet &pk)
+{
+    if (pk.release) pk.release(pk.opaque);
+    if (pk.own.p) p->spare.push_back(pk.own);
+    pk = Packet();
+}
 
 static void run_slot(htj2k_pipe *p, Slot *s)
 {
     std::vector<const uint8_t *> ptr(s->pkts.size());
     std::vector<int> len(s->pkts.size());
-    for (size_t i = 0; i < s->pkts.size(); i++) { ptr[i] = s->pkts[i].data; len[i] = s->pkts[i].size; }
-    int r = htj2k_job_parse_batch(p->ctx, ptr.data(), len.data(), (int)ptr.size(), &s->job);
+    std::vector<uint8_t> pinned(s->pkts.size());
+    for (size_t i = 0; i < s->pkts.size(); i++) { ptr[i] = s->pkts[i].data; len[i] = s->pkts[i].size; pinned[i] = s->pkts[i].own.p != nullptr; }
+    /* the pipe's own packet copies sit in page-locked memory and outlive the upload: no second staging copy */
+    int r = htj2k_job_parse_batch_ex(p->ctx, ptr.data(), len.data(), (int)ptr.size(), pinned.data(), &s->job);
     if (r >= 0) r = htj2k_job_upload(p->ctx, s->job);
     if (r >= 0) r = htj2k_job_run(p->ctx, s->job);
     if (r >= 0) r = htj2k_job_wait(p->ctx, s->job);
@@ -87,6 +100,7 @@ static void start_slot(htj2k_pipe *p, Slot &s)
     s.state = SLOT_RUNNING;
     s.rc = 0;
     s.next_out = 0;
+    s.device_handout = false;
     if (s.worker.joinable()) s.worker.join();
     s.worker = std::thread(run_slot, p, &s);
 }
@@ -122,13 +136,24 @@ extern "C" int htj2k_pipe_send(htj2k_pipe *p, const uint8_t *pkt, int size)
     std::unique_lock<std::mutex> lk(p->m);
     Slot &s = p->slots[p->fill];
     if (s.state != SLOT_FREE && s.state != SLOT_FILLING) return HTJ2K_ERR_EAGAIN;      /* receive first */
-    /* private copy with the input padding an AVPacket carries (AV_INPUT_BUFFER_PADDING_SIZE) */
+    /* private copy with the input padding an AVPacket carries (AV_INPUT_BUFFER_PADDING_SIZE), in page-locked memory:
+     * the H2D transfer starts from this very copy */
     Packet pk;
-    pk.own = new (std::nothrow) uint8_t[(size_t)size + PIPE_PAD];
-    if (!pk.own) return HTJ2K_ERR_ENOMEM;
-    memcpy(pk.own, pkt, (size_t)size);
-    memset(pk.own + size, 0, PIPE_PAD);
-    pk.data = pk.own;
+    const size_t need = (size_t)size + PIPE_PAD;
+    for (size_t i = 0; i < p->spare.size(); i++)
+        if (p->spare[i].cap >= need) { pk.own = p->spare[i]; p->spare.erase(p->spare.begin() + (long)i); break; }
+    if (!pk.own.p) {
+        if (p->spare.size() > 4 * (size_t)p->batch * (size_t)p->depth) {   /* too small for this stream: do not hoard them */
+            htj2k_host_free(p->ctx, p->spare.back().p);
+            p->spare.pop_back();
+        }
+        pk.own.cap = need + need / 4;
+        pk.own.p = (uint8_t *)htj2k_host_alloc(p->ctx, pk.own.cap);
+        if (!pk.own.p) return HTJ2K_ERR_ENOMEM;
+    }
+    memcpy(pk.own.p, pkt, (size_t)size);
+    memset(pk.own.p + size, 0, PIPE_PAD);
+    pk.data = pk.own.p;
     pk.size = size;
     return queue_packet(p, pk);
 }
@@ -171,13 +196,24 @@ static int due_slot(htj2k_pipe *p, std::unique_lock<std::mutex> &lk, Slot **out)
     return 0;
 }
 
+/* caller holds the lock.  A batch whose frames went out as device pointers keeps its job untouched until the frames of
+ * depth - 1 further batches have been handed out (what htj2k_pipe_receive_device promises): its slot is HELD, and
+ * htj2k_pipe_send answers EAGAIN when it comes round to it. */
 static void pop_frame(htj2k_pipe *p, Slot &s)
 {
-    s.pkts[s.next_out].drop();
+    drop_packet(p, s.pkts[s.next_out]);
     if (++s.next_out >= (int)s.pkts.size()) {
         s.pkts.clear();
         s.next_out = 0;
-        s.state = SLOT_FREE;
+        p->batches_out++;
+        if (s.device_handout && p->depth > 1) {
+            s.state = SLOT_HELD;
+            s.release_at = p->batches_out + p->depth - 1;
+        } else {
+            s.state = SLOT_FREE;
+        }
+        for (Slot &o : p->slots)
+            if (o.state == SLOT_HELD && p->batches_out >= o.release_at) o.state = SLOT_FREE;
         p->out = (p->out + 1) % p->depth;
     }
 }
@@ -229,15 +265,18 @@ extern "C" int htj2k_pipe_receive_device(htj2k_pipe *p, htj2k_frame *frame)
     lk.unlock();
     if (s->rc >= 0) {
         r = htj2k_job_device_frame(p->ctx, s->job, s->next_out, frame);
-    } else {                                               /* failed batch: this packet alone */
+    } else {                                               /* failed batch: this packet alone, in a job of its own that lives as long as the slot's */
         const Packet &pk = s->pkts[s->next_out];
-        r = htj2k_job_parse(p->ctx, pk.data, pk.size, &p->single);
-        if (r >= 0) r = htj2k_job_upload(p->ctx, p->single);
-        if (r >= 0) r = htj2k_job_run(p->ctx, p->single);
-        if (r >= 0) r = htj2k_job_wait(p->ctx, p->single);
-        if (r >= 0) r = htj2k_job_device_frame(p->ctx, p->single, 0, frame);
+        if ((int)s->retry.size() <= s->next_out) s->retry.resize((size_t)s->next_out + 1, nullptr);
+        htj2k_job **one = &s->retry[(size_t)s->next_out];
+        r = htj2k_job_parse(p->ctx, pk.data, pk.size, one);
+        if (r >= 0) r = htj2k_job_upload(p->ctx, *one);
+        if (r >= 0) r = htj2k_job_run(p->ctx, *one);
+        if (r >= 0) r = htj2k_job_wait(p->ctx, *one);
+        if (r >= 0) r = htj2k_job_device_frame(p->ctx, *one, 0, frame);
     }
     lk.lock();
+    if (r >= 0) s->device_handout = true;
     pop_frame(p, *s);
     return r;
 }
@@ -260,8 +299,11 @@ extern "C" void htj2k_pipe_close(htj2k_pipe *p)
     for (Slot &s : p->slots) {
         if (s.worker.joinable()) s.worker.join();
         if (s.job) htj2k_job_free(p->ctx, s.job);
-        for (size_t i = (s.state == SLOT_FREE ? s.pkts.size() : (size_t)s.next_out); i < s.pkts.size(); i++) s.pkts[i].drop();
+        for (htj2k_job *j : s.retry) if (j) htj2k_job_free(p->ctx, j);
+        for (size_t i = (s.state == SLOT_FREE || s.state == SLOT_HELD ? s.pkts.size() : (size_t)s.next_out); i < s.pkts.size(); i++)
+            drop_packet(p, s.pkts[i]);
     }
     if (p->single) htj2k_job_free(p->ctx, p->single);
+    for (PinBuf &b : p->spare) htj2k_host_free(p->ctx, b.p);
     delete p;
 }

@@ -139,6 +139,11 @@ int  htj2k_job_parse(htj2k_ctx *ctx, const uint8_t *pkt, int pkt_size, htj2k_job
  * device stage of the whole batch is ONE launch */
 int  htj2k_job_parse_batch(htj2k_ctx *ctx, const uint8_t *const *pkts, const int *pkt_sizes, int nframes,
                            htj2k_job **job);
+/* as htj2k_job_parse_batch; pinned[i] != 0 says that packet i lies in page-locked memory (htj2k_host_alloc) and stays
+ * valid and unchanged until htj2k_job_upload's transfers are done (htj2k_job_wait): the H2D copy then starts from the
+ * packet itself and the staging copy is left out.  pinned == NULL: none is. */
+int  htj2k_job_parse_batch_ex(htj2k_ctx *ctx, const uint8_t *const *pkts, const int *pkt_sizes, int nframes,
+                              const uint8_t *pinned, htj2k_job **job);
 int  htj2k_job_num_frames(const htj2k_job *job);
 /* host cost of the last htj2k_job_parse(_batch), per frame and per thread that worked on it: `ms_parse` the marker +
  * Tier-2 parse (no code-block byte is read with "device_gather", the default), `ms_stage` the copy of the packet
@@ -214,7 +219,8 @@ int  htj2k_job_num_blocks(const htj2k_job *job);
 /* device addresses of the decoded planes of frame `frame` of the job (data[] = device pointers), for callers that
  * keep frames on the GPU; valid until the job is parsed again */
 int  htj2k_job_device_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
-/* device address of an output plane, for callers that keep decoded frames on the GPU */
+/* device address of an output plane, for callers that keep decoded frames on the GPU.  Call htj2k_job_wait first: the
+ * planes of a run are final only after it (htj2k_job_device_frame waits by itself) */
 void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
 /* tuning / test knobs:
  *   "idwt_mode"   0 generic closed-form kernels, 1 LDS tile kernel, 2 LDS + DPP tile kernel,
@@ -238,6 +244,9 @@ int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
  * with htj2k_host_free as the free callback.  Plain pageable planes work everywhere, only slower. */
 void *htj2k_host_alloc(htj2k_ctx *ctx, size_t size);
 void  htj2k_host_free(htj2k_ctx *ctx, void *ptr);
+/* copies `size` bytes of a device plane handed out by htj2k_pipe_receive_device / htj2k_job_device_frame to host memory
+ * (a consumer that keeps frames on the GPU and wants one on the host after all); synchronous */
+int   htj2k_device_to_host(htj2k_ctx *ctx, void *dst, const void *device_src, size_t size);
 
 /* ---- asynchronous pipeline: packets in, frames out, in order (csrc/htj2k_pipe.cpp) ----
  * The throughput path for a stream of frames.  It takes the place of FFmpeg's frame threads
@@ -263,7 +272,9 @@ int  htj2k_pipe_flush(htj2k_pipe *pipe);
 int  htj2k_pipe_info(htj2k_pipe *pipe, htj2k_info *info);
 int  htj2k_pipe_receive(htj2k_pipe *pipe, htj2k_frame *out);
 /* as htj2k_pipe_receive without the copy: `out->data[]` are the device pointers of the decoded planes; they stay
- * valid until the pipe has handed out the frames of `depth - 1` further batches (the job is then reused) */
+ * valid until the pipe has handed out all frames of `depth - 1` further batches: the batch's job is kept back that
+ * long (htj2k_pipe_send answers HTJ2K_ERR_EAGAIN when it would need it), so a consumer of device frames has
+ * `depth - 1` batches in flight, not `depth` */
 int  htj2k_pipe_receive_device(htj2k_pipe *pipe, htj2k_frame *out);
 int  htj2k_pipe_skip(htj2k_pipe *pipe);
 void htj2k_pipe_close(htj2k_pipe *pipe);

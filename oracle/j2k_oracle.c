@@ -81,7 +81,16 @@ typedef struct BitState {
     uint32_t bits, tmp, last;
     uint8_t  bits_left;
     uint64_t bit_buf;
+    /* instrumentation, not part of the reference: a backward reader that has run out of stream keeps handing out bits
+     * (zeros, then its first byte over and over: `pos` is pinned to 0).  `fake` counts those bits; once a decoder has
+     * consumed into them (`under`), the block's result depends on that quirk.  Only corrupt blocks do that. */
+    uint32_t fake;
+    uint8_t  pinned, under;
 } BitState;
+
+/* set by orc_ht_decode_block: bit 0 the VLC reader, bit 1 the MagRef reader of the last block consumed bits that were
+ * not in the stream (tests use it to tell the one documented corner where the device path reads zeros instead) */
+static __thread int ht_block_notes;
 
 typedef struct MelState { uint8_t k, run, one; } MelState;   /* :82-86 */
 
@@ -96,6 +105,8 @@ static void refill_backwards(BitState *b, const uint8_t *a)
     uint32_t new_bits = 32;
 
     b->last = a[b->pos + 1];
+    if (b->bits_left < b->fake)
+        b->under = 1;
     if (b->bits_left >= 32)
         return;
     if (b->pos >= 3) {
@@ -106,6 +117,8 @@ static void refill_backwards(BitState *b, const uint8_t *a)
         tmp = (tmp << 8) | b->last;
         b->pos -= 4;
     } else {
+        b->fake += 8u * (uint32_t)(b->pinned ? 4 : 3 - b->pos);     /* bytes in front of the stream, or byte 0 once more */
+        b->pinned = 1;
         if (b->pos >= 2) tmp = a[b->pos - 2];
         if (b->pos >= 1) tmp = (tmp << 8) | a[b->pos - 1];
         if (b->pos >= 0) tmp = (tmp << 8) | a[b->pos];
@@ -444,6 +457,8 @@ static int ht_cleanup(const uint8_t *Dcup, uint32_t Lcup, uint32_t Pcup, uint8_t
         }
     }
 
+    if (vlc.under || vlc.bits_left < vlc.fake)
+        ht_block_notes |= 1;
     /* raster conversion, :976-1007 */
     {
         const uint8_t *sp = sig;
@@ -551,6 +566,8 @@ static void ht_magref(int width, int height, int stride, const uint8_t *Dref, ui
                     samples[j + i * stride] &= tmp;
                     samples[j + i * stride] |= 1 << (q - 1);
                 }
+    if (mr.under || mr.bits_left < mr.fake)
+        ht_block_notes |= 2;
 }
 
 /* ff_jpeg2000_decode_htj2k, jpeg2000htdec.c:1188-1336.
@@ -569,6 +586,7 @@ ORC_EXPORT int orc_ht_decode_block(uint8_t *data, int Lcup, int Lref, int npasse
     int p0, z_blk, num_plhd, rem, S_blk, pLSB, ret, x, y;
     uint32_t Scup, Pcup;
 
+    ht_block_notes = 0;
     for (y = 0; y < height; y++)
         memset(out + (size_t)y * out_stride, 0, (size_t)width * sizeof(*out));
     if (npasses == 0)
@@ -891,6 +909,8 @@ typedef struct OrcFrame {
     const J2kPlan *plan;
     int32_t *coef;          /* all planes; float planes alias the same storage */
     int n_block_errors;
+    uint8_t *notes;         /* per block: ht_block_notes of its decode */
+    int n_underrun_blocks;
 } OrcFrame;
 
 ORC_EXPORT OrcFrame *orc_frame_new(void)
@@ -906,22 +926,31 @@ ORC_EXPORT void orc_frame_free(OrcFrame *f)
     if (!f) return;
     orc_parser_free(f->parser);
     free(f->coef);
+    free(f->notes);
     free(f);
 }
 
-/* parse + tile_codeblocks() up to (not incl.) the IDWT: HT decode + dequant of every block */
-ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size, const htj2k_opts *opts)
+/* host parsing alone (jpeg2000dec.c:2825-2881 up to the tile fan-out) */
+ORC_EXPORT int orc_frame_parse(OrcFrame *f, const uint8_t *pkt, int size, const htj2k_opts *opts)
 {
-    const J2kPlan *pl;
+    free(f->coef); f->coef = NULL; f->n_block_errors = 0;
+    return orc_parse(f->parser, pkt, size, opts, 0, &f->plan);
+}
+
+/* tile_codeblocks() of a parsed frame up to (not incl.) the IDWT: block decode + dequant of every block */
+ORC_EXPORT int orc_frame_decode_parsed(OrcFrame *f)
+{
+    const J2kPlan *pl = f->plan;
     int ret, i;
     int32_t *t1 = NULL;
     uint8_t *scratch = NULL;
 
-    free(f->coef); f->coef = NULL; f->n_block_errors = 0;
-    ret = orc_parse(f->parser, pkt, size, opts, 0, &f->plan);
-    if (ret < 0)
-        return ret;
-    pl = f->plan;
+    if (!pl)
+        return HTJ2K_ERR_EINVAL;
+    free(f->coef); f->n_block_errors = 0;
+    free(f->notes);
+    f->notes = (uint8_t *)calloc((size_t)pl->nblocks + 1, 1);
+    f->n_underrun_blocks = 0;
     f->coef = (int32_t *)calloc(pl->nsamples + 64, sizeof(int32_t));
     t1 = (int32_t *)malloc(sizeof(int32_t) * 4096);
     scratch = (uint8_t *)malloc(65536 + 64);
@@ -942,6 +971,10 @@ ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size
             memcpy(scratch, pl->bytes + b->data_off, (size_t)b->lcup + b->lref + 8);
             ret = orc_ht_decode_block(scratch, b->lcup, b->lref, b->npasses, b->zbp, b->w, b->h, b->M_b,
                                       b->roi_shift, b->flags & J2K_CBLK_VSC, t1, b->w);
+            if (f->notes && ht_block_notes) {
+                f->notes[i] = (uint8_t)ht_block_notes;
+                f->n_underrun_blocks++;
+            }
         }
         if (ret < 0)
             f->n_block_errors++;                    /* HT: block left zero; Part-1: the passes decoded so far stay
@@ -957,6 +990,23 @@ ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size
     }
     free(t1); free(scratch);
     return 0;
+}
+
+/* parse + orc_frame_decode_parsed */
+ORC_EXPORT int orc_frame_decode_blocks(OrcFrame *f, const uint8_t *pkt, int size, const htj2k_opts *opts)
+{
+    const int ret = orc_frame_parse(f, pkt, size, opts);
+    return ret < 0 ? ret : orc_frame_decode_parsed(f);
+}
+
+/* blocks of the last decode whose VLC (bit 0) or MagRef (bit 1) reader consumed bits that were not in the stream;
+ * notes[i] per block, plus each block's window: plane_off, w, h, stride */
+ORC_EXPORT int orc_frame_underrun_blocks(OrcFrame *f) { return f->n_underrun_blocks; }
+ORC_EXPORT int orc_frame_block_note(OrcFrame *f, int i, uint32_t *plane_off, int *w, int *h, int *stride)
+{
+    if (!f->plan || !f->notes || i < 0 || i >= f->plan->nblocks) return HTJ2K_ERR_EINVAL;
+    *plane_off = f->plan->blocks[i].plane_off; *w = f->plan->blocks[i].w; *h = f->plan->blocks[i].h; *stride = f->plan->blocks[i].stride;
+    return f->notes[i];
 }
 
 ORC_EXPORT int orc_frame_idwt(OrcFrame *f)

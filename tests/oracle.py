@@ -60,7 +60,8 @@ def lib():
         L.orc_frame_new.restype = ctypes.c_void_p
         L.orc_frame_plane.restype = ctypes.c_void_p
         L.orc_vlc_table.restype = ctypes.POINTER(ctypes.c_uint16)
-        for n in ("orc_frame_free", "orc_frame_decode_blocks", "orc_frame_idwt", "orc_frame_write", "orc_frame_info",
+        for n in ("orc_frame_free", "orc_frame_decode_blocks", "orc_frame_parse", "orc_frame_decode_parsed", "orc_frame_underrun_blocks",
+                  "orc_frame_block_note", "orc_frame_idwt", "orc_frame_write", "orc_frame_info",
                   "orc_frame_bytes_consumed", "orc_frame_block_errors", "orc_frame_num_blocks",
                   "orc_frame_num_tilecomps", "orc_frame_tilecomp_dims", "orc_frame_plane", "orc_decode", "orc_probe"):
             getattr(L, n).argtypes = None
@@ -149,6 +150,46 @@ class OracleDecoder:
         r = self.L.orc_frame_decode_blocks(self.h, self._pkt(data), len(data), ctypes.byref(o))
         if r < 0:
             raise DecodeError(r)
+
+    def parse(self, data, **kw):
+        """host parsing alone; decode_parsed() / idwt() / write() carry on from it"""
+        o = make_opts(**kw)
+        r = self.L.orc_frame_parse(self.h, self._pkt(data), len(data), ctypes.byref(o))
+        if r < 0:
+            raise DecodeError(r)
+
+    def decode_parsed(self):
+        r = self.L.orc_frame_decode_parsed(self.h)
+        if r < 0:
+            raise DecodeError(r)
+
+    def write(self):
+        """mct + write_frame of the decoded, inverse-transformed frame -> (info, [plane arrays])"""
+        info = Info()
+        self.L.orc_frame_info(self.h, ctypes.byref(info))
+        planes, fr = alloc_frame(info)
+        r = self.L.orc_frame_write(self.h, ctypes.byref(fr))
+        if r < 0:
+            raise DecodeError(r)
+        return info, planes_to_arrays(info, planes)
+
+    def underrun_blocks(self):
+        """blocks of the last decode whose VLC / MagRef reader consumed bits beyond its stream (corrupt blocks only)"""
+        return self.L.orc_frame_underrun_blocks(self.h)
+
+    def underrun_windows(self):
+        """[(plane_off, w, h, stride)] of those blocks in the frame's coefficient buffer"""
+        out = []
+        po, w, h, st = ctypes.c_uint32(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for i in range(self.num_blocks()):
+            if self.L.orc_frame_block_note(self.h, i, ctypes.byref(po), ctypes.byref(w), ctypes.byref(h), ctypes.byref(st)) > 0:
+                out.append((po.value, w.value, h.value, st.value))
+        return out
+
+    def plane_offset(self, tc):
+        """sample offset of a tile-component's plane in the coefficient buffer (plane 0 starts at 0)"""
+        base = self.L.orc_frame_plane(self.h, 0)
+        return (self.L.orc_frame_plane(self.h, tc) - base) // 4
 
     def idwt(self):
         r = self.L.orc_frame_idwt(self.h)
