@@ -321,7 +321,7 @@ static int ht_cleanup(const uint8_t *Dcup, uint32_t Lcup, uint32_t Pcup, uint8_t
     size_t nq4 = (size_t)4 * qw * qh;
     uint8_t *sig, *E;
     uint32_t *mu;
-    BitState ms, mel, vlc;
+    BitState ms, mel, vlc = { 0 };
     MelState mst = { 0, 0, 0 };
     uint16_t ctx_run = 0;
     int row, ret = 1;
@@ -451,14 +451,21 @@ static int ht_cleanup(const uint8_t *Dcup, uint32_t Lcup, uint32_t Pcup, uint8_t
                 U[k] = kappa[k] + u[k];
             }
             for (k = 0; k < npair; k++)
-                if (U[k] > maxbp) { ret = HTJ2K_ERR_INVALIDDATA; goto done; }   /* :715,756,889,961 */
+                if (U[k] > maxbp) {                                                /* :715,756,889,961 */
+                    if (getenv("ORC_TRACE"))
+                        fprintf(stderr, "  U %d > maxbp %d at quad row %d, quad %d (kappa %d, u %d, rho %d); MagSgn pos %d/%u MEL pos %d/%u VLC pos %d under %d\n",
+                                U[k], maxbp, row, qx + k, kappa[k], u[k], s[k].rho, ms.pos, Pcup, mel.pos, Lcup, vlc.pos, vlc.under || vlc.bits_left < vlc.fake);
+                    ret = HTJ2K_ERR_INVALIDDATA;
+                    goto done;
+                }
             for (k = 0; k < npair; k++)
                 quad_magsgn(&ms, row * qw + qx + k, U[k], &s[k], sig, E, mu, Dcup, Pcup, pLSB);
         }
     }
 
-    if (vlc.under || vlc.bits_left < vlc.fake)
-        ht_block_notes |= 1;
+    if (getenv("ORC_TRACE"))
+        fprintf(stderr, "  cleanup %dx%d Lcup %u Pcup %u: MagSgn pos %d bits_left %d (past end: %d), MEL pos %d (Lcup %u), VLC pos %d under %d\n",
+                width, height, Lcup, Pcup, ms.pos, ms.bits_left, ms.pos >= (int)Pcup, mel.pos, Lcup, vlc.pos, vlc.under || vlc.bits_left < vlc.fake);
     /* raster conversion, :976-1007 */
     {
         const uint8_t *sp = sig;
@@ -478,11 +485,18 @@ static int ht_cleanup(const uint8_t *Dcup, uint32_t Lcup, uint32_t Pcup, uint8_t
                 states[(j1 + 1) * stride + (j2 + 2)] |= sp[2] * x2;
                 samples[(j2 + 1) + (j1 + 1) * stride] = (int32_t)mp[3] * x3;
                 states[(j1 + 2) * stride + (j2 + 2)] |= sp[3] * x3;
+                /* (x3 = x1 | x2, jpeg2000htdec.c:985: on ONE border of an odd-sized block the lower right sample of a quad
+                 * is kept although it lies outside the block.  A conforming stream codes nothing there; a corrupt one can
+                 * leave a significant phantom sample that SigProp then sees as a neighbour.  Instrumentation: note bit 2.) */
+                if (sp[3] && x3 && !(x1 && x2))
+                    ht_block_notes |= 4;
                 sp += 4;
                 mp += 4;
             }
     }
 done:
+    if (sig && (vlc.under || vlc.bits_left < vlc.fake))
+        ht_block_notes |= 1;                         /* also when the block ends in an error: where it ends depends on those bits */
     free(sig); free(E); free(mu);
     return ret;
 }
@@ -542,6 +556,12 @@ static void ht_sigprop(int causal, int width, int height, int stride, const uint
         int gh = imin(4, height - i);
         for (j = 0; j < width; j += 4)
             sigprop_group(&sp, i, j, imin(4, width - j), gh, stride, q, samples, states, Dref, Lref, causal);
+    }
+    if (getenv("ORC_TRACE")) {
+        uint32_t k;
+        fprintf(stderr, "  sigprop %dx%d: read %d of %u Dref bytes (bits left in the last %u):", width, height, sp.pos, Lref, sp.bits);
+        for (k = 0; k < Lref; k++) fprintf(stderr, " %02x", Dref[k]);
+        fprintf(stderr, "\n");
     }
 }
 
@@ -616,12 +636,21 @@ ORC_EXPORT int orc_ht_decode_block(uint8_t *data, int Lcup, int Lref, int npasse
 
     /* maxbp = cblk->zbp + 2 after cblk->zbp = S_blk - 1 (:605, :1263) */
     ret = ht_cleanup(data, Lcup, Pcup, (uint8_t)pLSB, (S_blk - 1) + 2, width, height, bw, samples, states);
+    if (getenv("ORC_TRACE"))
+        fprintf(stderr, "  block %dx%d npasses %d zbp %d M_b %d Lcup %d Lref %d Scup %u: cleanup returns %d\n", width, height, npasses, zbp, M_b, Lcup, Lref, Scup, ret);
     if (ret < 0)
         goto done;
+    if (z_blk <= 1)
+        ht_block_notes &= ~4;                       /* phantom samples only matter to SigProp */
+#define ORC_TRACE_ROW(tag) if (getenv("ORC_TRACE_ROW")) { int r_ = atoi(getenv("ORC_TRACE_ROW")), x_; if (r_ < height + 2) { \
+        fprintf(stderr, "  %s row %d:", tag, r_); for (x_ = 0; x_ < width; x_++) fprintf(stderr, " %08x/%02x", (unsigned)samples[x_ + r_ * bw], states[(r_ + 1) * bw + x_ + 1]); fprintf(stderr, "\n"); } }
+    ORC_TRACE_ROW("cleanup")
     if (z_blk > 1)
         ht_sigprop(vsc, width, height, bw, data + Lcup, Lref, (uint8_t)(pLSB - 1), samples, states);
+    ORC_TRACE_ROW("sigprop")
     if (z_blk > 2)
         ht_magref(width, height, bw, data + Lcup, Lref, (uint8_t)(pLSB - 1), samples, states);
+    ORC_TRACE_ROW("magref")
 
     for (y = 0; y < height; y++)
         for (x = 0; x < width; x++) {
