@@ -176,39 +176,6 @@ def cpu_baselines(streams, budget_s=10.0):
     return one, hot_path, allc
 
 
-def two_jobs_leg(dec, packets, steps):
-    """The same frames as two jobs on two HIP streams (not part of `value`, N=1 only): the instruction-bound HT kernels
-    of one job run beside the bandwidth-bound IDWT launches of the other.  It is reported beside `value` and not as
-    `value` because the IDWT launches then share the chip, and `roofline` is defined per launch (bench.py --jobs 2
-    measures everything that way)."""
-    import torch
-    jobs = [dec.job().parse_batch(packets[i::2]) for i in range(2)]
-    for job in jobs:
-        job.upload()
-    for job in jobs:
-        job.wait()
-    for _ in range(2):
-        for job in jobs:
-            job.run(7)
-    for job in jobs:
-        job.wait()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        for job in jobs:
-            job.run(7)
-        for job in jobs:
-            job.stage_ms()                                 # as in the timed region: the step's events are read
-    for job in jobs:
-        job.wait()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    for job in jobs:
-        job.free()
-    return {"value": round(steps * len(packets) * WIDTH * HEIGHT / dt / 1e6, 2), "unit": "Mpixel/s", "jobs": 2,
-            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4)}
-
-
 def part1_leg(dec, nframes, with_cpu):
     """the bench's 4K RGB frames coded with Part-1 (MQ) codeblocks, default mode switches, device-resident like `value`"""
     import ffmpeg_ht_amd
@@ -312,8 +279,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=48, help="4K frames per step and per GPU (16 GB of HBM at 48; the rate is flat from 16: 66 -> 69 Gpixel/s)")
-    ap.add_argument("--jobs", type=int, default=1, help="the batch is split over this many jobs (HIP streams): the "
-                    "latency-bound VLC kernel of one job overlaps the bandwidth-bound kernels of the other")
+    ap.add_argument("--jobs", type=int, default=2, help="the batch is split over this many jobs on HIP streams of their own, as the "
+                    "frame pipeline keeps several jobs in flight: the instruction-bound HT kernels of one job run beside the "
+                    "bandwidth-bound IDWT launches of the other.  `roofline` always comes from a separate pass of ONE job "
+                    "holding the whole batch, where every IDWT launch has the chip to itself")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank (cycled to fill the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--part1", type=int, default=0, metavar="FRAMES",
@@ -388,24 +357,14 @@ def main():
     for job in jobs:
         job.wait()
     barrier()
+    follow = os.environ.get("HTJ2K_BENCH_FOLLOW", "1") != "0"
     t0 = time.perf_counter()
-    ht_ms = idwt_ms = pack_ms = 0.0
-    idwt_launch_ms, idwt_launch_bytes, idwt_launch_hbm = 0.0, 0.0, 0.0
-    nlaunch = 0
     for _ in range(args.steps):
         for job in jobs:
             job.run(7)
-        # the per-stage / per-launch HIP events are read after the step's stream work is done
-        for job in jobs:
-            a, b, c = job.stage_ms()
-            ht_ms += a
-            idwt_ms += b
-            pack_ms += c
-            for (ms, by), hb in zip(job.idwt_launches(), job.idwt_hbm_bytes()):
-                idwt_launch_ms += ms
-                idwt_launch_bytes += by
-                idwt_launch_hbm += hb
-                nlaunch += 1
+        if follow:
+            for job in jobs:
+                job.stage_ms()          # the host follows the streams step by step (reads the step's events)
     for job in jobs:
         job.wait()
     barrier()
@@ -432,10 +391,39 @@ def main():
     if not parity:
         sys.exit("bench.py: the timed frames do not match their sources / the oracle (block errors: %d)" % block_errors)
 
-    # (before the host legs create and destroy their streams: the two jobs' streams should sit on hardware queues of their own)
-    two_jobs = None
-    if njobs == 1 and not args.no_e2e and world == 1 and args.batch >= 2:
-        two_jobs = two_jobs_leg(dec, per_job[0], max(5, args.steps // 2))
+    # `roofline` pass: the whole batch as ONE job, nothing else on the chip, per-launch HIP events on the job's stream
+    def measure_one_job(job, steps):
+        acc = dict(ht=0.0, idwt=0.0, pack=0.0, lms=0.0, lby=0.0, lhb=0.0, n=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.run(7)
+            a, b, c = job.stage_ms()
+            acc["ht"] += a; acc["idwt"] += b; acc["pack"] += c
+            for (ms, by), hb in zip(job.idwt_launches(), job.idwt_hbm_bytes()):
+                acc["lms"] += ms; acc["lby"] += by; acc["lhb"] += hb; acc["n"] += 1
+        job.wait()
+        torch.cuda.synchronize()
+        acc["seconds"] = time.perf_counter() - t0
+        acc["steps"] = steps
+        return acc
+    if njobs == 1:
+        rjob, own_rjob = jobs[0], False
+    else:
+        rjob, own_rjob = dec.job().parse_batch([m.packet(x) for x in batch]).upload(), True
+        for _ in range(2):
+            rjob.run(7)
+        rjob.wait()
+    rf = measure_one_job(rjob, max(5, args.steps // 2))
+    one_job = {"value": round(rf["steps"] * args.batch * WIDTH * HEIGHT / rf["seconds"] / 1e6, 2), "unit": "Mpixel/s",
+               "steps": rf["steps"], "ms_per_step": round(rf["seconds"] / rf["steps"] * 1e3, 4),
+               "note": "the batch as one job, stages strictly one after the other: the pass `roofline` and the stage times come from"}
+    c16, ll16 = bool(rjob.coef16()), rjob.ll16() == 1
+    if own_rjob:
+        rjob.free()
+    ht_ms, idwt_ms, pack_ms = rf["ht"], rf["idwt"], rf["pack"]
+    idwt_launch_ms, idwt_launch_bytes, idwt_launch_hbm, nlaunch = rf["lms"], rf["lby"], rf["lhb"], rf["n"]
+    rsteps = rf["steps"]
 
     # end-to-end rate of one frame through the plain htj2k_decode() entry (parse + H2D + kernels + D2H)
     n_e2e = 0 if (args.no_e2e or rank != 0 or world > 1) else 8       # the host-side legs: rank 0 of the N = 1 run only
@@ -501,8 +489,7 @@ def main():
     if rank == 0:
         algorithmic = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
         achieved = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
-        traffic = committed_traffic(args.batch) if njobs == 1 else None
-        c16, ll16 = bool(jobs[0].coef16()), jobs[0].ll16() == 1
+        traffic = committed_traffic(args.batch)
         res = {
             "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3) at 1/2/4/8 GPU; IDWT HBM GB/s vs peak",
             "value": round(value, 2),
@@ -518,9 +505,9 @@ def main():
             "data": "synthetic",
             "parity_checked": True,
             "config": {"workload": "configs[1]: 3840x2160 RGB 8-bit lossless 5/3 + RCT, 64x64 codeblocks, 5 levels, "
-                                   "single tile, HT cleanup pass only; %d frames per step per GPU in %d concurrent "
-                                   "jobs (HIP streams), device-resident input (codeblock bytes + descriptors) and "
-                                   "output (rgb24)" % (args.batch, njobs),
+                                   "single tile, HT cleanup pass only; %d frames per step per GPU as %d concurrent "
+                                   "jobs (HIP streams; the frame pipeline keeps that many in flight), device-resident input "
+                                   "(codeblock bytes + descriptors) and output (rgb24)" % (args.batch, njobs),
                        "frames_per_step": args.batch, "jobs": njobs, "codeblocks_per_step": nblocks,
                        "distinct_frames": len(streams), "block_errors": block_errors,
                        "sharding": "frames round-robin over ranks, no collective"},
@@ -538,15 +525,17 @@ def main():
                          "algorithmic_MB_per_launch": round(idwt_launch_bytes / max(nlaunch, 1) / 1e6, 3),
                          "copy_ceiling": COPY_CEILING_GBS,
                          "sub_bands_16bit": c16, "ll_bands_16bit": ll16,
+                         "measured": "separate pass after the timed region: the same batch as one job, %d steps, every IDWT launch alone on the chip" % rsteps,
                          "note": "achieved / frac count the bytes the launches have to move through HBM (per sample: sub-bands "
                                  "read as 2 B where sub_bands_16bit, LL bands read and written as 2 B where ll_bands_16bit -- "
                                  "checked on the device, the transform runs again with int32 if one does not fit -- 4 B otherwise; "
                                  "the final level writes the rgb24 frame, 1 B per sample); algorithmic_GBps is SURVEY 8(d)'s "
                                  "4 B + 4 B per sample and level over the same time: a rate, not a share of the bus; `traffic` "
                                  "is what the PMC counters saw per launch"},
-            "stage_ms_per_step_sum_over_jobs": {"ht_decode_dequant": round(ht_ms / args.steps, 4),
-                                                "idwt": round(idwt_ms / args.steps, 4),
-                                                "mct_pack": round(pack_ms / args.steps, 4)},
+            "stage_ms_per_step_one_job": {"ht_decode_dequant": round(ht_ms / rsteps, 4),
+                                          "idwt": round(idwt_ms / rsteps, 4),
+                                          "mct_pack": round(pack_ms / rsteps, 4)},
+            "one_job": one_job,
             "host": {"parse_ms_per_frame_one_core": round(sum(h[0] for h in host_ms) / len(host_ms), 3),
                      "staging_copy_ms_per_frame_one_core": round(sum(h[1] for h in host_ms) / len(host_ms), 3),
                      "parse_batch_wall_ms_per_frame": round(t_parse / args.batch * 1e3, 3),
@@ -573,8 +562,6 @@ def main():
                                       "packets-to-frames pipeline against whole oracle decodes"}
         if args.part1 > 0:
             res["part1"] = part1_leg(dec, args.part1, not args.no_cpu_baseline)
-        if two_jobs:
-            res["two_jobs"] = two_jobs
         if stream240:
             res["stream240"] = stream240
         print(json.dumps(res), flush=True)
