@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhtj2k_amd.so")
+LIB_PATH = os.environ.get("HTJ2K_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhtj2k_amd.so")   # HTJ2K_LIB: A/B builds side by side (tools/)
 
 ERR_NAMES = {-0x41444E49: "INVALIDDATA", -0x45574150: "PATCHWELCOME", -0x21475542: "BUG", -0x20545845: "EXTERNAL",
              -12: "ENOMEM", -22: "EINVAL", -38: "ENOSYS"}

@@ -42,6 +42,22 @@ ERR = {-0x41444E49: "INVALIDDATA", -0x45574150: "PATCHWELCOME", -0x21475542: "BU
        -38: "ENOSYS", -0x20545845: "EXTERNAL"}
 
 
+BLOCK_DTYPE = np.dtype([("data_off", "<u4"), ("plane_off", "<u4"), ("lcup", "<u2"), ("lref", "<u2"), ("w", "<u2"), ("h", "<u2"),
+                        ("stride", "<u2"), ("npasses", "u1"), ("zbp", "u1"), ("M_b", "u1"), ("flags", "u1"), ("roi_shift", "u1"),
+                        ("tcomp", "u1"), ("f_step", "<f4"), ("i_step", "<i4")])
+assert BLOCK_DTYPE.itemsize == 32
+
+
+class Plan(ctypes.Structure):
+    """struct J2kPlan of oracle/j2k_oracle_plan.h (the oracle's frozen copy of the descriptor layout)"""
+    _fields_ = [("info", Info), ("bytes_consumed", ctypes.c_int32), ("precision", ctypes.c_int32), ("out_bytes", ctypes.c_int32),
+                ("out_shift_precision", ctypes.c_int32), ("ntiles", ctypes.c_int32), ("ntilecomps", ctypes.c_int32),
+                ("tilecomps", ctypes.c_void_p), ("nblocks", ctypes.c_int32), ("blocks", ctypes.c_void_p), ("bytes", ctypes.c_void_p),
+                ("nbytes", ctypes.c_size_t), ("nsamples", ctypes.c_size_t), ("max_lcup", ctypes.c_uint32), ("max_lref", ctypes.c_uint32),
+                ("max_pcup", ctypes.c_uint32), ("max_scup", ctypes.c_uint32), ("max_qw", ctypes.c_uint32), ("max_bm_words", ctypes.c_uint32),
+                ("have_part1", ctypes.c_int32), ("palette", ctypes.c_uint32 * 256)]
+
+
 class DecodeError(RuntimeError):
     def __init__(self, code):
         super().__init__("decode failed: %s (%d)" % (ERR.get(code, "?"), code))
@@ -150,6 +166,24 @@ class OracleDecoder:
         r = self.L.orc_frame_decode_blocks(self.h, self._pkt(data), len(data), ctypes.byref(o))
         if r < 0:
             raise DecodeError(r)
+
+    def plan_blocks(self, data, **kw):
+        """the oracle parser's block table (numpy structured array, fields of struct J2kBlock)"""
+        L = self.L
+        L.orc_parser_new.restype = ctypes.c_void_p
+        p = ctypes.c_void_p(L.orc_parser_new())
+        try:
+            o = make_opts(**kw)
+            plan = ctypes.POINTER(Plan)()
+            buf = self._pkt(data)
+            r = L.orc_parse(p, buf, len(data), ctypes.byref(o), 0, ctypes.byref(plan))
+            if r < 0:
+                raise DecodeError(r)
+            n = plan.contents.nblocks
+            raw = ctypes.string_at(plan.contents.blocks, n * BLOCK_DTYPE.itemsize)
+            return np.frombuffer(raw, dtype=BLOCK_DTYPE).copy()
+        finally:
+            L.orc_parser_free(p)
 
     def parse(self, data, **kw):
         """host parsing alone; decode_parsed() / idwt() / write() carry on from it"""

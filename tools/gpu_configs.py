@@ -21,20 +21,37 @@ cfgs = {
     "C4 8K gray16 5/3 L6":           lambda: vecgen.encode(img(7680, 4320, 1, 16, 4), depth=16, nlevels=6, cb=(6, 6), transform=1),
     "C4 8K rgb48 5/3 L6 mct":        lambda: vecgen.encode(img(7680, 4320, 3, 16, 5), depth=16, mct=1, nlevels=6, cb=(6, 6), transform=1),
 }
+import json
 dec = m.Decoder()
+for kv in os.environ.get("KNOBS", "").split(","):
+    if "=" in kv: dec.set_int(kv.split("=")[0], int(kv.split("=")[1]))
+NB = {"C2": 48, "C3": 32, "C4 8K gray16": 16, "C4 8K rgb48": 8}      # frames per job: a few GB of planes each
+out = {}
 for name, mk in cfgs.items():
+    if len(sys.argv) > 1 and not any(a in name for a in sys.argv[1:]): continue
     t0 = time.time(); data = mk(); te = time.time() - t0
     pk = m.packet(data)
-    nb = 4
+    nb = next(v for k, v in NB.items() if name.startswith(k))
     job = dec.job().parse_batch([pk] * nb); job.upload(); job.wait()
     for _ in range(2): job.run()
     job.wait()
-    acc = np.zeros(3)
-    for _ in range(5):
+    acc = np.zeros(3); lms = lhb = lalg = 0.0; per = {}
+    R = 5
+    for _ in range(R):
         job.run(); job.wait(); acc += np.array(job.stage_ms())
-    acc /= 5
+        for i, ((ms, by), hb) in enumerate(zip(job.idwt_launches(), job.idwt_hbm_bytes())):
+            lms += ms; lalg += by; lhb += hb
+            e = per.setdefault(i, [0.0, 0.0]); e[0] += ms; e[1] += hb
+    acc /= R
     info = job.frame_info(0)
     px = info.width * info.height * nb
-    print("%-28s %5.1f MB  ht %.3f  idwt %.3f  pack %.3f ms per %d frames -> %.1f Gpixel/s  blocks %d errs %d (enc %.1fs)" % (
-        name, len(data) / 1e6, acc[0], acc[1], acc[2], nb, px / acc.sum() / 1e6, job.num_blocks(), job.block_errors(), te), flush=True)
+    frac = lhb / (lms * 1e-3) / 8e12
+    print("%-28s %5.1f MB  ht %.3f  idwt %.3f  pack %.3f ms per %d frames -> %.1f Gpixel/s  blocks %d errs %d  IDWT %.0f GB/s of bytes that move = %.3f of 8 TB/s (algorithmic %.0f GB/s) coef16 %d ll16 %d" % (
+        name, len(data) / 1e6, acc[0], acc[1], acc[2], nb, px / acc.sum() / 1e6, job.num_blocks(), job.block_errors(),
+        lhb / (lms * 1e-3) / 1e9, frac, lalg / (lms * 1e-3) / 1e9, job.coef16(), job.ll16()), flush=True)
+    print("      launches (us, MB, TB/s):", "  ".join("%.0f/%.0f/%.2f" % (v[0] / R * 1e3, v[1] / R / 1e6, v[1] / v[0] / 1e9) for v in per.values()), flush=True)
+    out[name] = dict(frames_per_job=nb, ht_ms=round(float(acc[0]), 4), idwt_ms=round(float(acc[1]), 4), Gpixel_s=round(px / acc.sum() / 1e6, 1),
+                     idwt_hbm_GBps=round(lhb / (lms * 1e-3) / 1e9, 1), idwt_frac_of_8TBps=round(frac, 4), idwt_algorithmic_GBps=round(lalg / (lms * 1e-3) / 1e9, 1),
+                     blocks=job.num_blocks(), coef16=bool(job.coef16()), ll16=job.ll16())
     job.free()
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
