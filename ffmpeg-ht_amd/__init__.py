@@ -79,7 +79,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
-           "htj2k_pipe_receive_device", "htj2k_job_device_frame", "htj2k_device_to_host",
+           "htj2k_pipe_receive_device", "htj2k_pipe_receive_device_ref", "htj2k_pipe_release_device", "htj2k_job_device_frame", "htj2k_device_to_host",
            "htj2k_splitter_open", "htj2k_splitter_find_end", "htj2k_splitter_parse", "htj2k_splitter_close",
            "htj2k_mxf_next_essence"]
 
@@ -382,6 +382,18 @@ class Pipe:
             return None
         _check(r, "htj2k_pipe_receive_device")
         return fr
+
+    def receive_device_ref(self):
+        """-> (Frame of device pointers, token) valid until release_device(token); None when nothing is in flight"""
+        fr, tok = Frame(), ctypes.c_uint64()
+        r = self.dec.L.htj2k_pipe_receive_device_ref(self.h, ctypes.byref(fr), ctypes.byref(tok))
+        if r == EAGAIN:
+            return None
+        _check(r, "htj2k_pipe_receive_device_ref")
+        return fr, tok.value
+
+    def release_device(self, token):
+        _check(self.dec.L.htj2k_pipe_release_device(self.h, ctypes.c_uint64(token)), "htj2k_pipe_release_device")
 
     def close(self):
         if self.h:

@@ -48,6 +48,8 @@ struct Slot {
     int next_out = 0;                  /* next frame of the batch to hand out */
     bool device_handout = false;       /* some frame of the batch left as device pointers */
     long release_at = 0;               /* SLOT_HELD: free again once this many batches have been handed out in full */
+    int outstanding = 0;               /* device frames handed out by htj2k_pipe_receive_device_ref and not released yet */
+    uint32_t generation = 0;           /* bumped every time the slot is started: stale release tokens are ignored */
     std::vector<htj2k_job *> retry;    /* failed batch, device hand-out: one single-frame job per frame (the pointers stay valid
                                         * as long as the slot's) */
     std::thread worker;
@@ -101,6 +103,8 @@ static void start_slot(htj2k_pipe *p, Slot &s)
     s.rc = 0;
     s.next_out = 0;
     s.device_handout = false;
+    s.outstanding = 0;
+    s.generation++;
     if (s.worker.joinable()) s.worker.join();
     s.worker = std::thread(run_slot, p, &s);
 }
@@ -190,7 +194,8 @@ extern "C" int htj2k_pipe_flush(htj2k_pipe *p)
 static int due_slot(htj2k_pipe *p, std::unique_lock<std::mutex> &lk, Slot **out)
 {
     Slot &s = p->slots[p->out];
-    if (s.state == SLOT_FREE || s.state == SLOT_FILLING) return HTJ2K_ERR_EAGAIN;
+    /* (HELD: its frames are all out and the consumer still has some of them; nothing behind it can have been started) */
+    if (s.state == SLOT_FREE || s.state == SLOT_FILLING || s.state == SLOT_HELD) return HTJ2K_ERR_EAGAIN;
     p->cv.wait(lk, [&] { return s.state == SLOT_DONE; });
     *out = &s;
     return 0;
@@ -210,10 +215,11 @@ static void pop_frame(htj2k_pipe *p, Slot &s)
             s.state = SLOT_HELD;
             s.release_at = p->batches_out + p->depth - 1;
         } else {
-            s.state = SLOT_FREE;
+            s.state = s.outstanding > 0 ? SLOT_HELD : SLOT_FREE;
+            s.release_at = 0;
         }
         for (Slot &o : p->slots)
-            if (o.state == SLOT_HELD && p->batches_out >= o.release_at) o.state = SLOT_FREE;
+            if (o.state == SLOT_HELD && p->batches_out >= o.release_at && o.outstanding == 0) o.state = SLOT_FREE;
         p->out = (p->out + 1) % p->depth;
     }
 }
@@ -279,6 +285,49 @@ extern "C" int htj2k_pipe_receive_device(htj2k_pipe *p, htj2k_frame *frame)
     if (r >= 0) s->device_handout = true;
     pop_frame(p, *s);
     return r;
+}
+
+/* as htj2k_pipe_receive_device, for consumers that keep frames for as long as they like (a reference-counted
+ * AVFrame): the batch's job is not reused before every frame handed out this way has been given back with
+ * htj2k_pipe_release_device(token) -- from any thread */
+extern "C" int htj2k_pipe_receive_device_ref(htj2k_pipe *p, htj2k_frame *frame, uint64_t *token)
+{
+    if (!p || !frame || !token) return HTJ2K_ERR_EINVAL;
+    int slot_index = 0;
+    uint32_t gen = 0;
+    {
+        std::unique_lock<std::mutex> lk(p->m);
+        Slot *s = nullptr;
+        int r = due_slot(p, lk, &s);
+        if (r < 0) return r;
+        slot_index = (int)(s - p->slots.data());
+        gen = s->generation;
+        s->outstanding++;                                  /* before the hand-out: pop_frame must see it */
+    }
+    const int r = htj2k_pipe_receive_device(p, frame);
+    std::unique_lock<std::mutex> lk(p->m);
+    Slot &s = p->slots[(size_t)slot_index];
+    if (r < 0) {
+        if (s.generation == gen && s.outstanding > 0) s.outstanding--;
+        if (s.state == SLOT_HELD && s.outstanding == 0 && p->batches_out >= s.release_at) s.state = SLOT_FREE;
+        return r;
+    }
+    s.release_at = 0;                                      /* explicit release rules this slot, not the depth - 1 rule */
+    if (s.state == SLOT_HELD && s.outstanding == 0) s.state = SLOT_FREE;
+    *token = ((uint64_t)(uint32_t)slot_index << 32) | gen;
+    return r;
+}
+
+extern "C" int htj2k_pipe_release_device(htj2k_pipe *p, uint64_t token)
+{
+    if (!p) return HTJ2K_ERR_EINVAL;
+    std::unique_lock<std::mutex> lk(p->m);
+    const size_t idx = (size_t)(token >> 32);
+    if (idx >= p->slots.size()) return HTJ2K_ERR_EINVAL;
+    Slot &s = p->slots[idx];
+    if (s.generation != (uint32_t)token || s.outstanding <= 0) return HTJ2K_ERR_EINVAL;
+    if (--s.outstanding == 0 && s.state == SLOT_HELD && p->batches_out >= s.release_at) s.state = SLOT_FREE;
+    return 0;
 }
 
 /* drop the next frame without copying it out (e.g. after htj2k_pipe_info reported an error) */

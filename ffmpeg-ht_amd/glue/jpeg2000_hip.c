@@ -29,7 +29,8 @@ typedef struct Jpeg2000HipContext {
 } Jpeg2000HipContext;
 
 /* enum htj2k_pix_fmt -> AVPixelFormat: the candidate lists of jpeg2000dec.c:170-193 */
-static const enum AVPixelFormat pix_map[HTJ2K_PIX_NB] = {
+/* (shared with glue/jpeg2000_hip_pipe.c and glue/jpeg2000_hip_hw.c) */
+const enum AVPixelFormat ff_jpeg2000_hip_pix_map[HTJ2K_PIX_NB] = {
     [HTJ2K_PIX_PAL8] = AV_PIX_FMT_PAL8, [HTJ2K_PIX_RGB24] = AV_PIX_FMT_RGB24, [HTJ2K_PIX_RGBA] = AV_PIX_FMT_RGBA,
     [HTJ2K_PIX_RGB48] = AV_PIX_FMT_RGB48, [HTJ2K_PIX_RGBA64] = AV_PIX_FMT_RGBA64,
     [HTJ2K_PIX_GRAY8] = AV_PIX_FMT_GRAY8, [HTJ2K_PIX_YA8] = AV_PIX_FMT_GRAY8A, [HTJ2K_PIX_GRAY16] = AV_PIX_FMT_GRAY16,
@@ -51,7 +52,7 @@ static const enum AVPixelFormat pix_map[HTJ2K_PIX_NB] = {
 static int to_htj2k_pix(enum AVPixelFormat f)
 {
     for (int i = 0; i < HTJ2K_PIX_NB; i++)
-        if (pix_map[i] == f)
+        if (ff_jpeg2000_hip_pix_map[i] == f)
             return i;
     return HTJ2K_PIX_NONE;
 }
@@ -99,7 +100,7 @@ static int jpeg2000_hip_decode_frame(AVCodecContext *avctx, AVFrame *picture, in
     avctx->profile = info.profile;
     if ((ret = ff_set_dimensions(avctx, info.width << avctx->lowres, info.height << avctx->lowres)) < 0)
         return ret;
-    avctx->pix_fmt = pix_map[info.pix_fmt];
+    avctx->pix_fmt = ff_jpeg2000_hip_pix_map[info.pix_fmt];
     avctx->bits_per_raw_sample = info.bits_per_raw_sample;
     if (info.lossless)
         avctx->properties |= FF_CODEC_PROPERTY_LOSSLESS;

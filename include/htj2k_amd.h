@@ -276,6 +276,13 @@ int  htj2k_pipe_receive(htj2k_pipe *pipe, htj2k_frame *out);
  * long (htj2k_pipe_send answers HTJ2K_ERR_EAGAIN when it would need it), so a consumer of device frames has
  * `depth - 1` batches in flight, not `depth` */
 int  htj2k_pipe_receive_device(htj2k_pipe *pipe, htj2k_frame *out);
+/* the same for consumers that keep frames for as long as they like (reference-counted frames: the AV_PIX_FMT_HIP
+ * hand-out of glue/jpeg2000_hip_hw.c): the planes stay valid until htj2k_pipe_release_device(token) -- callable from
+ * any thread, e.g. an AVBuffer free callback; until then the batch's job is not reused.  A consumer that sits on
+ * frames of all `depth` batches starves the pipe (htj2k_pipe_send keeps answering HTJ2K_ERR_EAGAIN): size `depth`
+ * for the frames the consumer holds, as extra_hw_frames does for hardware decoders. */
+int  htj2k_pipe_receive_device_ref(htj2k_pipe *pipe, htj2k_frame *out, uint64_t *token);
+int  htj2k_pipe_release_device(htj2k_pipe *pipe, uint64_t token);
 int  htj2k_pipe_skip(htj2k_pipe *pipe);
 void htj2k_pipe_close(htj2k_pipe *pipe);
 

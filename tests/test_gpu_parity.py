@@ -1026,3 +1026,49 @@ def test_two_devices_in_one_process(orc):
     assert not errors, errors
     for i in range(len(pkts)):
         assert all(np.array_equal(a, b) for a, b in zip(results[i], want[i])), i
+
+
+def test_pipe_device_frames_with_explicit_release(dec, orc):
+    """htj2k_pipe_receive_device_ref / htj2k_pipe_release_device (what a reference-counted AV_PIX_FMT_HIP frame needs):
+    frames held across many later batches keep their pixels; a consumer sitting on frames of every batch gets EAGAIN
+    from send until it releases one; stale tokens are refused"""
+    names = ["rgb_mct", "gray_l5_cb64", "yuv420p8", "gray16"]
+    pkts = [streams.get(names[i % len(names)])[0] for i in range(40)]
+    want = [orc.decode(p)[1] for p in pkts[:len(names)]]
+    pipe = dec.pipe(batch=2, depth=3)
+    try:
+        sent = got = 0
+        held = []                                             # (index, info, frame, token)
+        starved = False
+        while got < len(pkts):
+            progressed = False
+            while sent < len(pkts) and pipe.send(pkts[sent]):
+                sent += 1; progressed = True
+            if sent == len(pkts):
+                pipe.flush()
+            import ffmpeg_ht_amd as m
+            info = m.Info()
+            r = dec.L.htj2k_pipe_info(pipe.h, ctypes.byref(info))
+            if r == m.EAGAIN:
+                # nothing in flight and send refused: every slot is pinned by frames we hold
+                assert len(held) >= 1 and not progressed
+                starved = True
+                i, inf, fr, tok = held.pop(0)
+                assert all(np.array_equal(a, b) for a, b in zip(dec.fetch_device_frame(inf, fr), want[i % len(names)])), i
+                pipe.release_device(tok)
+                continue
+            assert r >= 0
+            fr, tok = pipe.receive_device_ref()
+            held.append((got, info, fr, tok))
+            got += 1
+            if len(held) > 9:                                  # keep the nine newest, check and release the oldest
+                i, inf, f0, t0 = held.pop(0)
+                assert all(np.array_equal(a, b) for a, b in zip(dec.fetch_device_frame(inf, f0), want[i % len(names)])), i
+                pipe.release_device(t0)
+                assert dec.L.htj2k_pipe_release_device(pipe.h, ctypes.c_uint64(t0)) == -22      # released twice
+        assert starved                                          # 9 held frames > 2 * 3 in flight: the pipe did run dry
+        for i, inf, fr, tok in held:
+            assert all(np.array_equal(a, b) for a, b in zip(dec.fetch_device_frame(inf, fr), want[i % len(names)])), i
+            pipe.release_device(tok)
+    finally:
+        pipe.close()
