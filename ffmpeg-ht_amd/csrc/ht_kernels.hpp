@@ -542,6 +542,71 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     uint32_t qi_next = (act && qh > 0) ? *qp : 0u;
     uint32_t E1p = 0, E3p = 0, ms_pos = 0;
     int err = 0;
+    /* The common case, taken when both blocks of the wave allow it: the magnitude LSB sits at or above the dequantiser's
+     * (pLSB >= 31 - M_b: every conforming stream) and a sample has at most 16 magnitude bits (maxbp <= 16; a larger U is
+     * an error that zeroes the block).  A quad then takes at most 64 MagSgn bits: one 96-bit LDS window per quad instead
+     * of two words per sample; the four bit counts, their prefix sums and the significance masks are bytes of one
+     * register (SWAR); the dequantiser is (t + 1) << (pLSB - dshift) | half bit, exact under those conditions.
+     * 180 -> ~125 VALU instructions per quad row in a kernel that is bound by instruction issue. */
+    const bool fast_blk = !ok || (pLSB >= dshift && pLSB >= 1 && pLSB <= 30 && maxbp <= 16);
+    if (__ballot(!fast_blk) == 0) {
+        const uint32_t up = (uint32_t)(pLSB - dshift) & 31u, hb = (halfbit & 0x7FFFFFFFu) >> (dshift & 31);
+        for (int row = 0; row < rows; row++) {
+            const bool arow = act && row < qh;
+            const uint32_t qi = qi_next;
+            qp += qwp;
+            qi_next = (act && row + 1 < qh) ? *qp : 0u;
+            const uint32_t rho = qi & 0xF, ek = (qi >> 4) & 0xF, e1 = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+            int kappa = 1;
+            if (row > 0) {
+                uint32_t l = ht_dpp_left(E3p), r = ht_dpp_right(E1p);
+                l = q == 0 ? 0u : l;
+                r = q == 31 ? 0u : r;
+                const int me = (int)max(max(E1p, E3p), max(l, r));
+                kappa = (rho & (rho - 1)) ? max(me - 1, 1) : 1;
+            }
+            const uint32_t U = (uint32_t)kappa + uq;
+            if (arow && (int)U > maxbp) err = 1;
+            /* bit k of a nibble -> bit 0 of byte k */
+            const uint32_t R = __umul24(rho, 0x204081u) & 0x01010101u, K = __umul24(ek, 0x204081u) & 0x01010101u;
+            const uint32_t Rm = (R << 8) - R;                               /* 0xFF in the bytes of significant samples */
+            const uint32_t U4 = __builtin_amdgcn_perm(U, U, 0x00000000u);   /* U in all four bytes (U < 256) */
+            const uint32_t N = (U4 - K) & Rm;                               /* m_n = sigma_n * U - k_n, one byte each (:883-888) */
+            const uint32_t S1 = N + (N << 8), S2 = S1 + (S1 << 16);          /* inclusive prefix sums of the four counts */
+            const uint32_t tot = S2 >> 24;
+            const uint32_t incl = half_incl_scan_u32(tot);
+            const uint32_t pos = ms_pos + incl - tot;
+            const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            ms_pos += hf ? end1 : end0;
+            const uint32_t wi = min(pos >> 5, last_wi + 1);
+            const uint32_t w0 = ms[wi], w1 = ms[wi + 1], w2 = ms[wi + 2];
+            uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pos), hi = __builtin_amdgcn_alignbit(w2, w1, pos);
+            const uint32_t n0 = N & 0xFF, n1 = (N >> 8) & 0xFF, n2 = (N >> 16) & 0xFF, n3 = N >> 24;
+            uint32_t v0 = __builtin_amdgcn_ubfe(lo, 0u, n0);
+            lo = __builtin_amdgcn_alignbit(hi, lo, n0); hi >>= (n0 & 31);
+            uint32_t v1 = __builtin_amdgcn_ubfe(lo, 0u, n1);
+            lo = __builtin_amdgcn_alignbit(hi, lo, n1); hi >>= (n1 & 31);
+            uint32_t v2 = __builtin_amdgcn_ubfe(lo, 0u, n2);
+            lo = __builtin_amdgcn_alignbit(hi, lo, n2);
+            uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, n3);
+            v0 += (e1 & 1) << n0; v1 += ((e1 >> 1) & 1) << n1; v2 += ((e1 >> 2) & 1) << n2; v3 += ((e1 >> 3) & 1) << n3;
+            const int s0m = -(int)(rho & 1), s1m = -(int)((rho >> 1) & 1), s2m = -(int)((rho >> 2) & 1), s3m = -(int)((rho >> 3) & 1);
+            E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
+            E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
+            auto sample = [&](uint32_t v, int sm) -> uint32_t {              /* mu (:407-427) -> dequantization_int */
+                const int r = (int)((((v >> 1) + 1u) << up) | hb);
+                const int sg = -(int)(v & 1);
+                return (uint32_t)(((r ^ sg) - sg) & sm);
+            };
+            /* low halves of two samples into one dword */
+            const uint32_t top = __builtin_amdgcn_perm(sample(v2, s2m), sample(v0, s0m), 0x05040100u);
+            const uint32_t bot = __builtin_amdgcn_perm(sample(v3, s3m), sample(v1, s1m), 0x05040100u);
+            const bool two = 2 * row + 1 < h;
+            *(arow ? (uint32_t *)prow : sink) = top;
+            *((arow && two) ? (uint32_t *)(prow + stride) : sink) = bot;
+            prow += 2 * stride;
+        }
+    } else
     for (int row = 0; row < rows; row++) {
         const bool arow = act && row < qh;
         const uint32_t qi = qi_next;
