@@ -50,7 +50,7 @@ struct HtLds {
 #define HT_MEL_SYMS  1344  /* MEL symbols a block can consume: <= 1024 quads + <= 256 first-row pairs, rounded up */
 #define HT_MEL_WORDS (HT_MEL_SYMS / 32 + 2)
 #define HT_UVLC_ENTRIES (5 * 64)
-#define HT_VSTAGE_PITCH 28                  /* dwords per lane: 24 staged + pad; 7 x 16 B keeps b128 writes conflict-free */
+#define HT_VSTAGE_PITCH 20                  /* dwords per lane: a ring of 16 stream words + the first 4 again behind it; 5 x 16 B keeps b128 writes conflict-free */
 #define HT_VSTAGE_BYTES (64 * HT_VSTAGE_PITCH * 4)
 
 /* quad symbols of a block in d_qsym: rows padded to an even number of quads (k_ht_vlc emits two
@@ -1424,11 +1424,18 @@ __host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
 }
 /* NARROW (every block of the launch at most 32 quads = 64 columns wide): the row-above significance a context
  * needs is two bits per quad and lives in two registers, and the flush bookkeeping is fetched from the owning lane
- * with ds_bpermute: 16 256 bytes of LDS, 10 instead of 8 waves per CU for this latency-bound kernel */
-#define HT_VLC_LDS_NARROW (4096 + 640 + HT_VSTAGE_BYTES + 64 * HT_VLC_OUT_PITCH * 4)
+ * with ds_bpermute.  Four waves share one copy of the decode tables, and the two stages turn over every 4 passes
+ * instead of every 8 (12 + 8 dwords per lane): 26 240 bytes of LDS per 256 blocks = 6 workgroups, 24 waves per CU
+ * where a wave with its own tables and 8-pass stages (16 256 bytes) allowed 10.  The bench job's 4741 waves are then
+ * resident at once (18.5 per CU) instead of running as two rounds of 2560, and the SIMDs have 4-5 serial chains each
+ * to interleave instead of 2.5. */
+#define HT_VLC_NARROW_WAVES 4
+#define HT_VLC_NARROW_VPITCH HT_VSTAGE_PITCH
+#define HT_VLC_NARROW_OPITCH HT_VLC_OUT_PITCH
+#define HT_VLC_LDS_NARROW (4096 + 640 + HT_VLC_NARROW_WAVES * 64 * (HT_VLC_NARROW_VPITCH + HT_VLC_NARROW_OPITCH) * 4)
 
 template <bool NARROW>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(NARROW ? 64 * HT_VLC_NARROW_WAVES : 64)
 k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
          const uint16_t *__restrict__ g_tables, uint32_t *__restrict__ qsym,
          const uint32_t *__restrict__ qoff, uint32_t max_qw,
@@ -1437,26 +1444,25 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     extern __shared__ __align__(16) uint8_t smem[];
     uint16_t *tbl = (uint16_t *)smem;
     uint16_t *utbl = (uint16_t *)(smem + 4096);          /* HT_UVLC_ENTRIES entries */
-    /* VLC words of every lane staged through LDS: 24 dwords (96 contiguous bytes) per lane are
-     * fetched once every 8 quad pairs and cover the 16 pairs after they are issued (16 x 38 bits
-     * + 31 < 768), so a lane touches 1-2 cache lines per refill instead of per pair */
-    uint32_t *vstage = (uint32_t *)(smem + 4096 + (NARROW ? 640 : 1024));
+    constexpr int CAD = 8;                               /* passes per flush of the output stage */
+    constexpr int VPITCH = NARROW ? HT_VLC_NARROW_VPITCH : HT_VSTAGE_PITCH, OPITCH = NARROW ? HT_VLC_NARROW_OPITCH : HT_VLC_OUT_PITCH;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *vstage = NARROW ? (uint32_t *)(smem + 4096 + 640) + wv * 64 * (VPITCH + OPITCH) : (uint32_t *)(smem + 4096 + 1024);
     /* output stage: the two quad symbols of a pass go to LDS; every 8 passes the wave writes the 64
      * lanes' 64-byte chunks out together, 4 lanes per chunk with 16-byte stores.  A lane storing
      * its own two dwords per pass made 128 separate line requests per pass and wave (every lane
      * writes into a different block's symbol array): that address traffic, not arithmetic, was
      * 40 % of this kernel's time. */
-    uint32_t *ostage = (uint32_t *)(smem + 4096 + (NARROW ? 640 : 1024) + HT_VSTAGE_BYTES);
+    uint32_t *ostage = NARROW ? vstage + 64 * VPITCH : (uint32_t *)(smem + 4096 + 1024 + HT_VSTAGE_BYTES);
     uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;   /* !NARROW only */
     /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
      * dwords is odd so the 64 lanes hit distinct banks */
     uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;                            /* !NARROW only */
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
-    const int lane = threadIdx.x;
-    const int bi = blockIdx.x * 64 + lane;
-    for (int i = lane; i < 1024; i += 64)
+    const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
         ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
-    for (int i = lane; i < HT_UVLC_ENTRIES; i += 64)
+    for (int i = threadIdx.x; i < HT_UVLC_ENTRIES; i += blockDim.x)
         utbl[i] = ht_uvlc_entry(i >> 6, (uint32_t)(i & 63));
 
     int qw = 0, qh = 0;
@@ -1500,10 +1506,18 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     const uint32_t *vsrc = vlc_u + doff;
     uint8_t *myrho = rho_rows + lane * pitch;
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
-    uint32_t *vst = vstage + lane * HT_VSTAGE_PITCH;
-    uint32_t *ost = ostage + lane * HT_VLC_OUT_PITCH;
-    uint4 nx[6];                                         /* words in flight for the refill after next */
-    uint32_t sbase = 0, nbase = 0;                       /* word index of vst[0] / of nx[0] */
+    uint32_t *vst = vstage + lane * VPITCH;
+    uint32_t *ost = ostage + lane * OPITCH;
+    /* VLC words: a ring of 16 per lane in LDS (vst[w & 15] = stream word w, words 0-3 of the ring repeated behind it
+     * so that the three words a pass reads are contiguous).  Every second pass a lane whose ring holds fewer than 8
+     * words beyond its position asks for the next 4; they are written to the ring two passes later.  Two passes take
+     * at most 76 bits, so a lane that did not ask still has 5 words at the next check, one that did has 6 (a pass
+     * reads 3 from a position at most 2 words further); the 4 slots written are at least 5 words behind the position.
+     * Every stream byte is fetched once: 24-dword windows re-requested every 8 passes fetched each byte ~7 times,
+     * and L2 requests, not arithmetic, bounded this kernel. */
+    uint4 nxv = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t hw = 16, pw = 0;                            /* words requested so far / word index of nxv */
+    bool pend = false;
     /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
      * up to six codewords (>= 6, typically >= 32 symbols).  The stream is read from the raw bytes Dcup[Pcup ...]
@@ -1515,34 +1529,34 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     __builtin_memcpy(&pfA, mraw - 1, 4);
     __builtin_memcpy(&pfB, mraw + 3, 4);
     __builtin_memcpy(&pfC, mraw + 7, 4);
-#pragma unroll
-    for (int jx = 0; jx < 6; jx++) nx[jx] = make_uint4(0u, 0u, 0u, 0u);
     if (qh > 0) {
 #pragma unroll
-        for (int jx = 0; jx < 6; jx++) {
+        for (int jx = 0; jx < 4; jx++) {
             uint4 q;
             __builtin_memcpy(&q, vsrc + 4 * jx, 16);
             *(uint4 *)(vst + 4 * jx) = q;
+            if (jx == 0) *(uint4 *)(vst + 16) = q;
         }
     }
-    /* the wave writes window `win` (passes 8 win .. 8 win + 7) of all lanes: 4 lanes per 64-byte chunk */
+    /* the wave writes window `win` (passes CAD win .. CAD win + CAD - 1) of all lanes: 4 (NARROW: 2) lanes per
+     * 64-byte (32-byte) chunk */
     auto flush = [&](int win) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int c = 16 * p + (lane >> 2), part = lane & 3;
-            const uint32_t *src = ostage + c * HT_VLC_OUT_PITCH + 4 * part;
+        for (int p = 0; p < CAD / 2; p++) {
+            const int c = (128 / CAD) * p + (lane / (CAD / 2)), part = lane & (CAD / 2 - 1);
+            const uint32_t *src = ostage + c * OPITCH + 4 * part;
             const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
             /* the symbol array and pass count of the lane that owns chunk c */
             const uint32_t c_lo = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_lo) : obase_lo[c];
             const uint32_t c_hi = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_hi) : obase_hi[c];
             const uint32_t c_nit = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, n_it) : onit[c];
-            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * 16 + 4 * part;
+            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * (2 * CAD) + 4 * part;
             /* chunks of lanes that are done (or never had a block) go to a scratch line: always four
              * stores, so that the wait for the staged VLC words can be counted (vmcnt) */
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(1))) u32x4 g_u32x4;    /* a global, not a FLAT, store */
             u32x4 vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
-            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * 8) < c_nit ? dst : sink + 4 * part) = vv;
+            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * CAD) < c_nit ? dst : sink + 4 * part) = vv;
         }
     };
 
@@ -1556,16 +1570,18 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         const uint16_t *table = tbl + (row ? 1024 : 0);
         const bool row0 = row == 0;
         const bool pair = qx + 1 < qw;
-        if ((t & 7) == 0) {
-            if (t) {                                     /* words requested 8 passes ago become the staged window */
-#pragma unroll
-                for (int jx = 0; jx < 6; jx++) *(uint4 *)(vst + 4 * jx) = nx[jx];
-                sbase = nbase;
+        if ((t & 1) == 0) {
+            if (pend) {
+                *(uint4 *)(vst + (pw & 15)) = nxv;
+                if ((pw & 15) == 0) *(uint4 *)(vst + 16) = nxv;
             }
-            nbase = vpos >> 5;
-#pragma unroll
-            for (int jx = 0; jx < 6; jx++) __builtin_memcpy(&nx[jx], vsrc + nbase + 4 * jx, 16);
-            if (t) flush((t >> 3) - 1);                  /* behind the loads: nothing waits for these stores for 8 passes */
+            pend = (int)(hw - (vpos >> 5)) < 8;
+            if (pend) {
+                __builtin_memcpy(&nxv, vsrc + hw, 16);
+                pw = hw;
+                hw += 4;
+            }
+            if ((t & (CAD - 1)) == 0 && t) flush(t / CAD - 1);   /* behind the load: nothing waits for these stores */
         }
         if (mcnt < 3) {                                  /* a pair uses at most 3 MEL symbols */
             /* >= 42 MEL bits from mrb, first bit in the MSB; six codewords need <= 36.  The twelve bytes were
@@ -1635,7 +1651,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         }
         uint64_t vwin;
         {
-            const uint32_t off = vpos - (sbase << 5), kw = off >> 5, sh = off & 31;
+            const uint32_t kw = (vpos >> 5) & 15, sh = vpos & 31;
             const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
             vwin = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
         }
@@ -1709,8 +1725,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 if (pair) myrho[qx + 1] = (uint8_t)rho[1];
             }
         }
-        ost[2 * (t & 7)] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
-        ost[2 * (t & 7) + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
+        ost[2 * (t & (CAD - 1))] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
+        ost[2 * (t & (CAD - 1)) + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
         /* next quad pair of this lane's block */
         qx += 2;
         if (active && qx >= qw) {
@@ -1720,7 +1736,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             else ra_next = (int)myrho[0];                /* above quad 0 of the new row */
         }
     }
-    if (max_it > 0) flush((max_it - 1) >> 3);
+    if (max_it > 0) flush((max_it - 1) / CAD);
 }
 
 }  // namespace htj2k

@@ -1322,7 +1322,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                            c->idwt_mode == 3 && c->fuse_pack;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
+                    HIP_TRY(c, hipFuncSetAttribute(vlc_narrow ? (const void *)k_ht_vlc<true> : (const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
@@ -1332,7 +1332,8 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
-                hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, j->stream,
+                const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
+                hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads + 32);
