@@ -569,11 +569,12 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             if (arow && (int)U > maxbp) err = 1;
             /* bit k of a nibble -> bit 0 of byte k */
             const uint32_t R = __umul24(rho, 0x204081u) & 0x01010101u, K = __umul24(ek, 0x204081u) & 0x01010101u;
-            const uint32_t Rm = (R << 8) - R;                               /* 0xFF in the bytes of significant samples */
+            uint32_t Rs = R << 8;
+            asm("" : "+v"(Rs));                                             /* (or the compiler makes it R * 255: v_mul_lo_u32 is quarter rate) */
+            const uint32_t Rm = Rs - R;                                     /* 0xFF in the bytes of significant samples */
             const uint32_t U4 = __builtin_amdgcn_perm(U, U, 0x00000000u);   /* U in all four bytes (U < 256) */
             const uint32_t N = (U4 - K) & Rm;                               /* m_n = sigma_n * U - k_n, one byte each (:883-888) */
-            const uint32_t S1 = N + (N << 8), S2 = S1 + (S1 << 16);          /* inclusive prefix sums of the four counts */
-            const uint32_t tot = S2 >> 24;
+            const uint32_t tot = __builtin_amdgcn_sad_u8(N, 0u, 0u);         /* sum of the four bytes */
             const uint32_t incl = half_incl_scan_u32(tot);
             const uint32_t pos = ms_pos + incl - tot;
             const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -601,9 +602,10 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             /* low halves of two samples into one dword */
             const uint32_t top = __builtin_amdgcn_perm(sample(v2, s2m), sample(v0, s0m), 0x05040100u);
             const uint32_t bot = __builtin_amdgcn_perm(sample(v3, s3m), sample(v1, s1m), 0x05040100u);
-            const bool two = 2 * row + 1 < h;
-            *(arow ? (uint32_t *)prow : sink) = top;
-            *((arow && two) ? (uint32_t *)(prow + stride) : sink) = bot;
+            if (arow) {
+                *(uint32_t *)prow = top;
+                if (2 * row + 1 < h) *(uint32_t *)(prow + stride) = bot;
+            }
             prow += 2 * stride;
         }
     } else
