@@ -551,11 +551,19 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const bool fast_blk = !ok || (pLSB >= dshift && pLSB >= 1 && pLSB <= 30 && maxbp <= 16);
     if (__ballot(!fast_blk) == 0) {
         const uint32_t up = (uint32_t)(pLSB - dshift) & 31u, hb = (halfbit & 0x7FFFFFFFu) >> (dshift & 31);
+        /* SIMPLE (wave-uniform): both blocks have the same, even, height -- nearly every wave, the block table is sorted
+         * by size.  Then which lanes store is fixed for the whole loop: lanes outside their block aim at the scratch
+         * line from the start (stride 0), and every row issues exactly two stores behind the prefetch of the next row's
+         * symbols, so that the wait at the loop top is vmcnt(2), not vmcnt(0) (see ht_magsgn_rows_narrow). */
+        auto fast_rows = [&](auto simple_tag) {
+        constexpr bool SIMPLE = decltype(simple_tag)::value;
+        uint16_t *pt = (SIMPLE && !act) ? (uint16_t *)sink : prow;
+        const int st = (SIMPLE && !act) ? 0 : stride;
         for (int row = 0; row < rows; row++) {
-            const bool arow = act && row < qh;
+            const bool arow = SIMPLE ? act : (act && row < qh);
             const uint32_t qi = qi_next;
             qp += qwp;
-            qi_next = (act && row + 1 < qh) ? *qp : 0u;
+            qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
             const uint32_t rho = qi & 0xF, ek = (qi >> 4) & 0xF, e1 = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
             int kappa = 1;
             if (row > 0) {
@@ -602,12 +610,20 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             /* low halves of two samples into one dword */
             const uint32_t top = __builtin_amdgcn_perm(sample(v2, s2m), sample(v0, s0m), 0x05040100u);
             const uint32_t bot = __builtin_amdgcn_perm(sample(v3, s3m), sample(v1, s1m), 0x05040100u);
-            if (arow) {
-                *(uint32_t *)prow = top;
-                if (2 * row + 1 < h) *(uint32_t *)(prow + stride) = bot;
+            if (SIMPLE) {
+                *(uint32_t *)pt = top;
+                *(uint32_t *)(pt + st) = bot;
+            } else {
+                const bool two = 2 * row + 1 < h;
+                *(arow ? (uint32_t *)pt : sink) = top;
+                *((arow && two) ? (uint32_t *)(pt + st) : sink) = bot;
             }
-            prow += 2 * stride;
+            pt += 2 * st;
         }
+        };
+        const int qh0 = __builtin_amdgcn_readlane(qh, 0), qh1 = __builtin_amdgcn_readlane(qh, 32);
+        if (qh0 == qh1 && __ballot(ok && (h & 1)) == 0) fast_rows(std::true_type{});
+        else fast_rows(std::false_type{});
     } else
     for (int row = 0; row < rows; row++) {
         const bool arow = act && row < qh;
