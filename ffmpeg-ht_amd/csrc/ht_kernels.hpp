@@ -55,6 +55,26 @@ struct HtLds {
 
 /* quad symbols of a block in d_qsym: rows padded to an even number of quads (k_ht_vlc emits two
  * per pass of its loop), the block rounded up to 16 words (its lanes flush 64-byte chunks) */
+/* One quad symbol is 16 bits: bits 0-7 four 2-bit fields, field n = rho_n + e_k,n + e_1,n of sample n (e_1 is only
+ * ever set where e_k is, e_k where rho is: 0 = not significant, 1 = significant, 2 = + known exponent bound, 3 = + known
+ * MSB), bits 8-15 the U-VLC value u (at most 2 + 5 + 31 + 4 * 15).  (Until round 2 a dword: rho | e_k << 4 | e_1 << 8 |
+ * u << 16 -- the symbol array was 1.24 GB written and read again per 48 4K frames.) */
+typedef uint16_t ht_sym_t;
+__host__ __device__ inline uint32_t ht_sym_pack_fields(uint32_t rho, uint32_t ek, uint32_t e1)
+{
+    uint32_t pk = 0;
+    for (int n = 0; n < 4; n++) pk |= (((rho >> n) & 1) + ((ek >> n) & 1) + ((e1 >> n) & 1)) << (2 * n);
+    return pk;
+}
+/* symbol -> rho | e_k << 4 | e_1 << 8 | u << 16 (the paths that are not bench-critical keep that form) */
+__device__ __forceinline__ uint32_t ht_sym_unpack(uint32_t s)
+{
+    const uint32_t pk = s & 0xFF, lo = pk & 0x55, hi = (pk >> 1) & 0x55;
+    uint32_t t = (lo | hi) | (hi << 8) | ((lo & hi) << 16);             /* >= 1, >= 2, == 3 at the even bits of bytes 0, 1, 2 */
+    t = (t | (t >> 1)) & 0x333333u;
+    t = (t | (t >> 2)) & 0x0F0F0Fu;
+    return (t & 0xF) | ((t >> 4) & 0xF0) | ((t >> 8) & 0xF00) | ((s >> 8) << 16);
+}
 __host__ __device__ inline uint32_t ht_qsym_pitch(uint32_t w) { return (((w + 1) >> 1) + 1) & ~1u; }
 __host__ __device__ inline uint32_t ht_qsym_words(uint32_t w, uint32_t h) { return (ht_qsym_pitch(w) * ((h + 1) >> 1) + 15) & ~15u; }
 
@@ -277,7 +297,7 @@ __device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict_
 /* C16: the plane is written as 16-bit samples (`dst` then points at int16_t elements; 5/3 blocks with M_b <= 15
  * only: every dequantised value fits, see htj2k_device.hip) */
 template <int TRANSFORM, bool REFINE, bool C16 = false>
-__device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict__ qglob, const uint32_t *ms,
+__device__ __forceinline__ int ht_magsgn_rows_narrow(const ht_sym_t *__restrict__ qglob, const uint32_t *ms,
                                                      uint32_t *__restrict__ dst, int lane, int w, int h,
                                                      int stride, int pLSB, int maxbp, int M_b, float fscale, int i_step,
                                                      uint32_t last_wi, uint32_t *__restrict__ sink,
@@ -297,7 +317,7 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
     uint32_t ms_pos = 0, Eb = 0;
     int err = 0;
     const int qwp = (int)ht_qsym_pitch((uint32_t)w);       /* k_ht_vlc pads the symbol rows to an even quad count */
-    const uint32_t *qp = qglob + q;
+    const ht_sym_t *qp = qglob + q;
     uint32_t qi_next = act ? *qp : 0u;
     uint32_t *prow = dst + col;                            /* this lane's column, row 2 * row */
     uint16_t *prow16 = (uint16_t *)dst + col;              /* the same under C16 */
@@ -305,11 +325,12 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const uint32_t *__restrict_
         const uint32_t qi = qi_next;
         qp += qwp;
         if (row + 1 < qh) qi_next = act ? *qp : 0u;
-        const uint32_t rho = qi & 0xF, uq = (qi >> 16) & 0xFF;
-        /* this lane's samples: top = bit sh, bottom = bit sh + 1 of rho / e_k / e_1 */
-        const uint32_t s_t = (qi >> sh) & 1, s_b = (qi >> (sh + 1)) & 1;
-        const uint32_t k_t = (qi >> (sh + 4)) & 1, k_b = (qi >> (sh + 5)) & 1;
-        const uint32_t e_t = (qi >> (sh + 8)) & 1, e_b = (qi >> (sh + 9)) & 1;
+        const uint32_t rho = (qi | (qi >> 1)) & 0x55, uq = qi >> 8;   /* significance at the even bits: only "more than one?" is asked */
+        /* this lane's samples: top = field sh, bottom = field sh + 1 */
+        const uint32_t f_t = (qi >> (2 * sh)) & 3, f_b = (qi >> (2 * sh + 2)) & 3;
+        const uint32_t s_t = min(f_t, 1u), s_b = min(f_b, 1u);
+        const uint32_t k_t = f_t >> 1, k_b = f_b >> 1;
+        const uint32_t e_t = (f_t + 1) >> 2, e_b = (f_b + 1) >> 2;
         int kappa = 1;
         if (row > 0) {
             /* own-lane neighbours cover columns c-1, c+1; together with the pair partner's
@@ -443,7 +464,7 @@ __device__ __forceinline__ uint32_t half_incl_scan_u32(uint32_t v)   /* inclusiv
 __global__ void __launch_bounds__(64)
 k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
                  uint32_t *__restrict__ coef, int *__restrict__ status, uint32_t ms_words,
-                 const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink)
+                 const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t *ms_all = (uint32_t *)smem;                     /* [2][ms_words + 4] */
@@ -536,7 +557,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const uint32_t last_wi = hf ? lastwi_h[1] : lastwi_h[0];
     const bool act = ok && q < qw;
     const int qwp = (int)ht_qsym_pitch((uint32_t)w);
-    const uint32_t *qp = qsym + qoff[bi] + q;
+    const ht_sym_t *qp = qsym + qoff[bi] + q;
     uint16_t *prow = (uint16_t *)coef + b.plane_off + 2 * q;     /* this quad's two columns, row 2 * row */
     const int rows = max(__builtin_amdgcn_readlane(qh, 0), __builtin_amdgcn_readlane(qh, 32));
     uint32_t qi_next = (act && qh > 0) ? *qp : 0u;
@@ -564,19 +585,20 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             const uint32_t qi = qi_next;
             qp += qwp;
             qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
-            const uint32_t rho = qi & 0xF, ek = (qi >> 4) & 0xF, e1 = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+            /* field n of the symbol -> bits 0-1 of byte n; R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
+            const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);           /* (ORs, not one multiply: the shifted copies overlap) */
+            const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1, uq = qi >> 8;
+            const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
             int kappa = 1;
             if (row > 0) {
                 uint32_t l = ht_dpp_left(E3p), r = ht_dpp_right(E1p);
                 l = q == 0 ? 0u : l;
                 r = q == 31 ? 0u : r;
                 const int me = (int)max(max(E1p, E3p), max(l, r));
-                kappa = (rho & (rho - 1)) ? max(me - 1, 1) : 1;
+                kappa = (R & (R - 1)) ? max(me - 1, 1) : 1;
             }
             const uint32_t U = (uint32_t)kappa + uq;
             if (arow && (int)U > maxbp) err = 1;
-            /* bit k of a nibble -> bit 0 of byte k */
-            const uint32_t R = __umul24(rho, 0x204081u) & 0x01010101u, K = __umul24(ek, 0x204081u) & 0x01010101u;
             uint32_t Rs = R << 8;
             asm("" : "+v"(Rs));                                             /* (or the compiler makes it R * 255: v_mul_lo_u32 is quarter rate) */
             const uint32_t Rm = Rs - R;                                     /* 0xFF in the bytes of significant samples */
@@ -598,8 +620,8 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             uint32_t v2 = __builtin_amdgcn_ubfe(lo, 0u, n2);
             lo = __builtin_amdgcn_alignbit(hi, lo, n2);
             uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, n3);
-            v0 += (e1 & 1) << n0; v1 += ((e1 >> 1) & 1) << n1; v2 += ((e1 >> 2) & 1) << n2; v3 += ((e1 >> 3) & 1) << n3;
-            const int s0m = -(int)(rho & 1), s1m = -(int)((rho >> 1) & 1), s2m = -(int)((rho >> 2) & 1), s3m = -(int)((rho >> 3) & 1);
+            v0 += (X1 & 1) << n0; v1 += ((X1 >> 8) & 1) << n1; v2 += ((X1 >> 16) & 1) << n2; v3 += (X1 >> 24) << n3;
+            const int s0m = -(int)(R & 1), s1m = -(int)((R >> 8) & 1), s2m = -(int)((R >> 16) & 1), s3m = -(int)(R >> 24);
             E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
             E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
             auto sample = [&](uint32_t v, int sm) -> uint32_t {              /* mu (:407-427) -> dequantization_int */
@@ -630,7 +652,8 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         const uint32_t qi = qi_next;
         qp += qwp;
         qi_next = (act && row + 1 < qh) ? *qp : 0u;
-        const uint32_t rho = qi & 0xF, ek = (qi >> 4) & 0xF, e1 = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
+        const uint32_t qx = ht_sym_unpack(qi);
+        const uint32_t rho = qx & 0xF, ek = (qx >> 4) & 0xF, e1 = (qx >> 8) & 0xF, uq = (qx >> 16) & 0xFF;
         int kappa = 1;
         if (row > 0) {
             /* exponents of the row above at columns 2q-1 .. 2q+2: the neighbours' come by DPP, nothing crosses the
@@ -697,7 +720,7 @@ template <bool EXTERNAL_VLC>
 __global__ void __launch_bounds__(64)
 k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
             uint32_t *__restrict__ coef, const uint16_t *__restrict__ g_tables,
-            int *__restrict__ status, HtLds L, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
+            int *__restrict__ status, HtLds L, const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
             uint32_t *__restrict__ sink, const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff,
             int coef16 = 0)
 {
@@ -817,7 +840,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
     S.suf = suf; S.mel_pos = 0; S.mel_len = Scup; S.mel_tmp = 0; S.mel_bits = 0;
     S.mel_k = 0; S.mel_run = 0; S.mel_one = 0;
     if (!EXTERNAL_VLC && lane == 0) S.vdrop(0), S.vfill(), S.vdrop(4);   /* jpeg2000_init_vlc drops the Scup nibble, :283-295 */
-    const uint32_t *qglob = EXTERNAL_VLC ? qsym + qoff[blockIdx.x] : nullptr;
+    const ht_sym_t *qglob = EXTERNAL_VLC ? qsym + qoff[blockIdx.x] : nullptr;
 
     float fscale = b.f_step;
     fscale /= (float)(1 << (31 - b.M_b));              /* jpeg2000dec.c:2104-2106 */
@@ -925,7 +948,7 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
             const int col = c0 + lane;
             const bool act = col < ncols;
             const int q = col >> 1;
-            const uint32_t qi = act ? (EXTERNAL_VLC ? qglob[row * (int)ht_qsym_pitch((uint32_t)w) + q] : qcur[q]) : 0;
+            const uint32_t qi = act ? (EXTERNAL_VLC ? ht_sym_unpack(qglob[row * (int)ht_qsym_pitch((uint32_t)w) + q]) : qcur[q]) : 0;
             const int rho = qi & 0xF, ekq = (qi >> 4) & 0xF, e1q = (qi >> 8) & 0xF, uq = (qi >> 16) & 0xFF;
             int kappa = 1;
             if (row > 0 && act) {                      /* :855-885; Eprev[-1] and Eprev[ncols] are 0 */
@@ -1275,7 +1298,7 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
  * applies while it dequantises.  ref_list[i] = block index, roff[block] = first mask of the block. */
 __global__ void __launch_bounds__(64)
 k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ ref_list, int nref,
-            const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
+            const uint8_t *__restrict__ bytes, const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
             const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u,
             uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
 {
@@ -1294,7 +1317,7 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     const int z_blk = b.npasses - plhd;
     if (z_blk <= 1) return;
     const bool causal = (b.flags & J2K_CBLK_VSC) != 0;
-    const uint32_t *qs = qsym + qoff[bi];
+    const ht_sym_t *qs = qsym + qoff[bi];
     const uint32_t nsw = ht_nsw(Scup), nsp = b.lref ? ht_nsp(b.lref) : 0;
     const uint32_t *spw = vlc_u + (b.data_off >> 2) + nsw, *mrw = mel_u + (b.data_off >> 2) + nsw;
     const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
@@ -1328,11 +1351,11 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     auto quad_rows = [&](int qy, uint64_t &top, uint64_t &bot) {
         top = 0; bot = 0;
         if (qy >= qh) return;
-        const uint32_t *row = qs + (size_t)qy * ht_qsym_pitch((uint32_t)w);
+        const ht_sym_t *row = qs + (size_t)qy * ht_qsym_pitch((uint32_t)w);
         for (int q = 0; q < qw; q++) {
-            const uint32_t rho = row[q] & 15u;
-            top |= (uint64_t)((rho & 1u) | ((rho >> 1) & 2u)) << (2 * q);            /* samples 0, 2 of the quad */
-            bot |= (uint64_t)(((rho >> 1) & 1u) | ((rho >> 2) & 2u)) << (2 * q);     /* samples 1, 3 */
+            const uint32_t sy = row[q], rho = (sy | (sy >> 1)) & 0x55u;               /* significance of sample n at bit 2 n */
+            top |= (uint64_t)((rho & 1u) | ((rho >> 3) & 2u)) << (2 * q);            /* samples 0, 2 of the quad */
+            bot |= (uint64_t)(((rho >> 2) & 1u) | ((rho >> 5) & 2u)) << (2 * q);     /* samples 1, 3 */
         }
         top &= wmask; bot &= wmask;
         if (2 * qy + 1 >= h) bot = 0;
@@ -1434,7 +1457,7 @@ __host__ __device__ inline uint16_t ht_uvlc_entry(int mode, uint32_t v)
 /* LDS of k_ht_vlc beyond the two decode tables: staged VLC words, the output stage (16 quad
  * symbols per lane, pitch 17) with the three words of flush bookkeeping per lane, and the
  * significance bytes of the row above */
-#define HT_VLC_OUT_PITCH 17
+#define HT_VLC_OUT_PITCH 9
 #define HT_VLC_OUT_BYTES (64 * (HT_VLC_OUT_PITCH + 3) * 4)
 __host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
 {
@@ -1455,7 +1478,7 @@ __host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
 template <bool NARROW>
 __global__ void __launch_bounds__(NARROW ? 64 * HT_VLC_NARROW_WAVES : 64)
 k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
-         const uint16_t *__restrict__ g_tables, uint32_t *__restrict__ qsym,
+         const uint16_t *__restrict__ g_tables, ht_sym_t *__restrict__ qsym,
          const uint32_t *__restrict__ qoff, uint32_t max_qw,
          const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u, uint32_t *__restrict__ sink)
 {
@@ -1478,14 +1501,17 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;                            /* !NARROW only */
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int bi = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
-        ((uint32_t *)tbl)[i] = ((const uint32_t *)g_tables)[i];
+    /* the decode tables with the symbol's four fields where e_k and e_1 were: u_off | len << 1 | rho << 4 | fields << 8 */
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
+        const uint32_t e = g_tables[i];
+        tbl[i] = (uint16_t)((e & 0xFF) | (ht_sym_pack_fields((e >> 4) & 0xF, (e >> 8) & 0xF, (e >> 12) & 0xF) << 8));
+    }
     for (int i = threadIdx.x; i < HT_UVLC_ENTRIES; i += blockDim.x)
         utbl[i] = ht_uvlc_entry(i >> 6, (uint32_t)(i & 63));
 
     int qw = 0, qh = 0;
     uint32_t doff = 0;
-    uint32_t *qout = qsym;
+    ht_sym_t *qout = qsym;
     const uint8_t *mraw = bytes + 16;                    /* Dcup + Pcup: the MEL bytes; lanes without a block read the pool's front pad */
     int mlim = 0;                                        /* Scup */
     if (bi < nblocks) {
@@ -1556,20 +1582,20 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (jx == 0) *(uint4 *)(vst + 16) = q;
         }
     }
-    /* the wave writes window `win` (passes CAD win .. CAD win + CAD - 1) of all lanes: 4 (NARROW: 2) lanes per
-     * 64-byte (32-byte) chunk */
+    /* the wave writes window `win` (passes CAD win .. CAD win + CAD - 1: 2 CAD symbols = 32 bytes) of all lanes: 2 lanes
+     * per chunk */
     auto flush = [&](int win) {
 #pragma unroll
-        for (int p = 0; p < CAD / 2; p++) {
-            const int c = (128 / CAD) * p + (lane / (CAD / 2)), part = lane & (CAD / 2 - 1);
+        for (int p = 0; p < 2; p++) {
+            const int c = 32 * p + (lane >> 1), part = lane & 1;
             const uint32_t *src = ostage + c * OPITCH + 4 * part;
             const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
             /* the symbol array and pass count of the lane that owns chunk c */
             const uint32_t c_lo = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_lo) : obase_lo[c];
             const uint32_t c_hi = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_hi) : obase_hi[c];
             const uint32_t c_nit = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, n_it) : onit[c];
-            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * (2 * CAD) + 4 * part;
-            /* chunks of lanes that are done (or never had a block) go to a scratch line: always four
+            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * CAD + 4 * part;
+            /* chunks of lanes that are done (or never had a block) go to a scratch line: always two
              * stores, so that the wait for the staged VLC words can be counted (vmcnt) */
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(1))) u32x4 g_u32x4;    /* a global, not a FLAT, store */
@@ -1675,7 +1701,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         }
         uint32_t m = (uint32_t)msyms, mused = 0;         /* next MEL symbols, LSB first */
         uint32_t a = (uint32_t)vwin, aused = 0;         /* the two codewords need <= 14 bits */
-        int rho[2], uoff[2], ek[2], e1[2];
+        int rho[2], uoff[2];
+        uint32_t pk[2];                                  /* the four 2-bit fields of the symbol */
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const bool en = active && (k == 0 || pair);
@@ -1701,7 +1728,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             const uint32_t e = dec ? table[(ctx << 7) | (a & 0x7F)] : 0u;
             const uint32_t len = (e >> 1) & 7;
             a >>= len; aused += len;
-            uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; ek[k] = (e >> 8) & 0xF; e1[k] = (e >> 12) & 0xF;
+            uoff[k] = e & 1; rho[k] = (e >> 4) & 0xF; pk[k] = e >> 8;
             if (en) {
                 rho_left = rho[k];
                 ral = ra;
@@ -1743,8 +1770,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 if (pair) myrho[qx + 1] = (uint8_t)rho[1];
             }
         }
-        ost[2 * (t & (CAD - 1))] = (uint32_t)rho[0] | ((uint32_t)ek[0] << 4) | ((uint32_t)e1[0] << 8) | ((uint32_t)u1 << 16);
-        ost[2 * (t & (CAD - 1)) + 1] = (uint32_t)rho[1] | ((uint32_t)ek[1] << 4) | ((uint32_t)e1[1] << 8) | ((uint32_t)u2 << 16);
+        ost[t & (CAD - 1)] = pk[0] | ((uint32_t)u1 << 8) | (pk[1] << 16) | ((uint32_t)u2 << 24);
         /* next quad pair of this lane's block */
         qx += 2;
         if (active && qx >= qw) {

@@ -1022,7 +1022,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t0.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
-    if ((r = j->d_qsym.ensure((j->nquads + 64) * sizeof(uint32_t))) < 0) return r;
+    if ((r = j->d_qsym.ensure(j->nquads * sizeof(ht_sym_t) + 256)) < 0) return r;      /* + the scratch line of k_ht_vlc's flush */
     if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
     /* a corrupt block can run k_ht_vlc's bit positions past its own arrays (38 VLC / 18 MEL bits per quad pair at
      * most, 4096 samples per block: < 3 KB): the last block of the pool must still read inside the allocation */
@@ -1335,25 +1335,25 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
                 hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                   (const uint16_t *)c->d_tables, (uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
-                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads + 32);
+                                   (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
+                                   (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
                 if (!j->reflist.empty())
                     hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, (const uint32_t *)j->d_reflist.p, (int)j->reflist.size(),
-                                       (const uint8_t *)j->d_bytes.p, (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                       (const uint8_t *)j->d_bytes.p, (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
                                        (uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
                 if (j->coef_is16 && j->pair_ok && c->ht_pair)
                     hipLaunchKernelGGL(k_ht_decode_pair, dim3((nblocks + 1) / 2), dim3(64), 2 * (j->lds_ext.ms_words + 4) * 4, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                        (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words,
-                                       (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                       (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (uint32_t *)j->d_coef.p + j->nsamples + 32);
                 else
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
-                                   (const uint32_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                   (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                    (uint32_t *)j->d_coef.p + j->nsamples + 32,
                                    (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p, j->coef_is16 ? 1 : 0);
             } else {
@@ -1362,7 +1362,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)j->d_coef.p + j->nsamples + 32,
+                                   (const ht_sym_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)j->d_coef.p + j->nsamples + 32,
                                    (const uint64_t *)nullptr, (const uint32_t *)nullptr);
             }
             HIP_TRY(c, hipGetLastError());
@@ -1976,16 +1976,16 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
             hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
             hipLaunchKernelGGL(k_ht_vlc<false>, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
-                               (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (uint32_t *)dq.p, (const uint32_t *)dqo.p,
-                               tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq + 32);
+                               (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (ht_sym_t *)dq.p, (const uint32_t *)dqo.p,
+                               tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq / 2 + 32);
             if (!reflist.empty())
                 hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
                                    (const J2kBlock *)db.p, (const uint32_t *)drl.p, (int)reflist.size(), (const uint8_t *)dby.p,
-                                   (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p,
+                                   (const ht_sym_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p,
                                    (uint64_t *)drb.p, (const uint32_t *)dro.p);
             hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), tmp.ext.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.ext,
-                               (const uint32_t *)dq.p, (const uint32_t *)dqo.p, (uint32_t *)dc.p + nsamples + 8,
+                               (const ht_sym_t *)dq.p, (const uint32_t *)dqo.p, (uint32_t *)dc.p + nsamples + 8,
                                (const uint64_t *)drb.p, (const uint32_t *)dro.p);
             e = hipDeviceSynchronize();
         }
@@ -1995,7 +1995,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), tmp.lds.total, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)dc.p, (const uint16_t *)c->d_tables, (int *)ds.p, tmp.lds,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)dc.p + nsamples + 8,
+                               (const ht_sym_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)dc.p + nsamples + 8,
                                (const uint64_t *)nullptr, (const uint32_t *)nullptr);
             e = hipDeviceSynchronize();
         }
