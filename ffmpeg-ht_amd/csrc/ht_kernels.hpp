@@ -50,7 +50,7 @@ struct HtLds {
 #define HT_MEL_SYMS  1344  /* MEL symbols a block can consume: <= 1024 quads + <= 256 first-row pairs, rounded up */
 #define HT_MEL_WORDS (HT_MEL_SYMS / 32 + 2)
 #define HT_UVLC_ENTRIES (5 * 64)
-#define HT_VSTAGE_PITCH 20                  /* dwords per lane: a ring of 16 stream words + the first 4 again behind it; 5 x 16 B keeps b128 writes conflict-free */
+#define HT_VSTAGE_PITCH 17                  /* dwords per lane: a ring of 16 stream words; odd, so that the lanes' reads fall into distinct banks */
 #define HT_VSTAGE_BYTES (64 * HT_VSTAGE_PITCH * 4)
 
 /* quad symbols of a block in d_qsym: rows padded to an even number of quads (k_ht_vlc emits two
@@ -1552,8 +1552,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
     uint32_t *vst = vstage + lane * VPITCH;
     uint32_t *ost = ostage + lane * OPITCH;
-    /* VLC words: a ring of 16 per lane in LDS (vst[w & 15] = stream word w, words 0-3 of the ring repeated behind it
-     * so that the three words a pass reads are contiguous).  Every second pass a lane whose ring holds fewer than 8
+    /* VLC words: a ring of 16 per lane in LDS (vst[w & 15] = stream word w).  Every second pass a lane whose ring holds fewer than 8
      * words beyond its position asks for the next 4; they are written to the ring two passes later.  Two passes take
      * at most 76 bits, so a lane that did not ask still has 5 words at the next check, one that did has 6 (a pass
      * reads 3 from a position at most 2 words further); the 4 slots written are at least 5 words behind the position.
@@ -1578,8 +1577,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         for (int jx = 0; jx < 4; jx++) {
             uint4 q;
             __builtin_memcpy(&q, vsrc + 4 * jx, 16);
-            *(uint4 *)(vst + 4 * jx) = q;
-            if (jx == 0) *(uint4 *)(vst + 16) = q;
+            vst[4 * jx] = q.x; vst[4 * jx + 1] = q.y; vst[4 * jx + 2] = q.z; vst[4 * jx + 3] = q.w;
         }
     }
     /* the wave writes window `win` (passes CAD win .. CAD win + CAD - 1: 2 CAD symbols = 32 bytes) of all lanes: 2 lanes
@@ -1616,8 +1614,8 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         const bool pair = qx + 1 < qw;
         if ((t & 1) == 0) {
             if (pend) {
-                *(uint4 *)(vst + (pw & 15)) = nxv;
-                if ((pw & 15) == 0) *(uint4 *)(vst + 16) = nxv;
+                uint32_t *r = vst + (pw & 15);
+                r[0] = nxv.x; r[1] = nxv.y; r[2] = nxv.z; r[3] = nxv.w;
             }
             pend = (int)(hw - (vpos >> 5)) < 8;
             if (pend) {
@@ -1696,7 +1694,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         uint64_t vwin;
         {
             const uint32_t kw = (vpos >> 5) & 15, sh = vpos & 31;
-            const uint32_t a0 = vst[kw], a1 = vst[kw + 1], a2 = vst[kw + 2];
+            const uint32_t a0 = vst[kw], a1 = vst[(kw + 1) & 15], a2 = vst[(kw + 2) & 15];
             vwin = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
         }
         uint32_t m = (uint32_t)msyms, mused = 0;         /* next MEL symbols, LSB first */
