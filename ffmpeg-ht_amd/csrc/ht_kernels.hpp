@@ -1604,9 +1604,10 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
 
     int ctx_run = 0, row = 0, qx = 0;
     int rho_left = 0, ral = 0, ra_next = 0;
-    /* NARROW: bit q of A1 / A3 = bit 1 / bit 3 of the significance pattern of quad q in the row above (the two samples
-     * of its lower row: all a context looks at, jpeg2000htdec.c:725-760); N1 / N3 collect the current row */
-    uint32_t A1 = 0, A3 = 0, N1 = 0, N3 = 0;
+    /* NARROW: bit 1 / bit 3 of the significance patterns of the row above (the two samples of a quad's lower row: all
+     * a context looks at, jpeg2000htdec.c:725-760), shifted along with the walk: bit j of A1 / A3 = quad qx + j, L1 / L3
+     * = quad qx - 1; bit q of N1 / N3 collects the current row */
+    uint32_t A1 = 0, A3 = 0, L1 = 0, L3 = 0, N1 = 0, N3 = 0;
     for (int t = 0; t < max_it; t++) {
         const bool active = t < n_it;
         const uint16_t *table = tbl + (row ? 1024 : 0);
@@ -1707,7 +1708,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             const int q = qx + k;
             int ra, rar, ctx;
             if (NARROW) {
-                const uint32_t a1 = q ? A1 >> (q - 1) : A1 << 1, a3 = q ? A3 >> (q - 1) : A3 << 1;   /* bit 0: quad q-1, bit 1: q, bit 2: q+1 */
+                const uint32_t a1 = k ? A1 : (A1 << 1) | L1, a3 = k ? A3 : (A3 << 1) | L3;             /* bit 0: quad q-1, bit 1: q, bit 2: q+1 */
                 ra = 0; rar = 0;
                 ctx = row0 ? ctx_run
                            : (int)((((a1 >> 1) | a3) & 1) | ((((uint32_t)rho_left >> 2) | ((uint32_t)rho_left >> 3)) & 1) << 1 |
@@ -1771,10 +1772,11 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         ost[t & (CAD - 1)] = pk[0] | ((uint32_t)u1 << 8) | (pk[1] << 16) | ((uint32_t)u2 << 24);
         /* next quad pair of this lane's block */
         qx += 2;
+        if (NARROW) { L1 = (A1 >> 1) & 1; L3 = (A3 >> 1) & 1; A1 >>= 2; A3 >>= 2; }
         if (active && qx >= qw) {
             qx = 0; row++;
             rho_left = 0; ral = 0;
-            if (NARROW) { A1 = N1; A3 = N3; N1 = 0; N3 = 0; }
+            if (NARROW) { A1 = N1; A3 = N3; L1 = 0; L3 = 0; N1 = 0; N3 = 0; }
             else ra_next = (int)myrho[0];                /* above quad 0 of the new row */
         }
     }
