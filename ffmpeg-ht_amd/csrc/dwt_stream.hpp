@@ -38,7 +38,10 @@
 
 namespace htj2k {
 
-#define STREAM_TW 244          /* output columns per wave: lanes 1..61 whole + slack for an odd origin; multiple of 4 */
+#define STREAM_TW 244          /* most output columns a wave can own: lanes 1..61 whole + slack for an odd origin; multiple of 4.
+                                * The host picks the strip width per launch (StreamGrid::tw <= STREAM_TW): a width whose
+                                * row of output bytes is a multiple of 64 keeps the stores of neighbouring strips out of
+                                * each other's lines where the plane is wide enough to pay for the idle lanes. */
 
 /* elementwise lifting steps on raw 32-bit samples: s1/s3 update an even sample from its odd
  * neighbours a, b; s2/s4 an odd sample from its even neighbours */
@@ -135,13 +138,13 @@ struct DwtFusedArgs {
 template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
-                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by,
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by,
                  int *__restrict__ ovf = nullptr, int ovf_bits = 16)
 {
     using O = LiftOps<TYPE>;
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
     const DwtLevel g = A[0].g;
-    const int x0 = bx * STREAM_TW, y0 = by * th;
+    const int x0 = bx * tw, y0 = by * th;
     if (x0 >= g.lh || y0 >= g.lv) return;
     const LineMap LX(g.mh, g.lh), LY(g.mv, g.lv);
     const int lane = threadIdx.x;
@@ -197,24 +200,24 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
          * low-horizontal half is the previous level's output */
         if (C16) {
             static_assert(!C16 || FAST, "16-bit sub-bands: fast path only");
-            auto lo16 = [](uint32_t v) { return (uint32_t)(int32_t)(int16_t)(v & 0xFFFFu); };
-            auto hi16 = [](uint32_t v) { return (uint32_t)((int32_t)v >> 16); };
+            /* The buffers carry the dwords as loaded -- two 16-bit samples each, in Lr[1], Hr[0], Hr[1] (and Lr[0] under
+             * LL16) -- and widen() makes samples of them when the step that uses them begins.  Widened here, the values
+             * that cross the loop's back edge are results of the loads, and the compiler waits for every load in flight
+             * (s_waitcnt vmcnt(0)) at the bottom of the loop: the next step's loads were not ahead of anything. */
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const uint16_t *b16 = (const uint16_t *)band_base + A[c].g.plane_off;
                 const uint16_t *brow0 = b16 + (size_t)iy[0] * A[c].g.stride, *brow1 = b16 + (size_t)iy[1] * A[c].g.stride;
-                const uint32_t lo = *(const uint32_t *)(brow0 + col[1]);        /* col[] are even here: aligned pairs */
-                const uint32_t he = *(const uint32_t *)(brow1 + col[0]), ho = *(const uint32_t *)(brow1 + col[1]);
+                Lr[c][1] = *(const uint32_t *)(brow0 + col[1]);                 /* col[] are even here: aligned pairs */
+                Hr[c][0] = *(const uint32_t *)(brow1 + col[0]);
+                Hr[c][1] = *(const uint32_t *)(brow1 + col[1]);
                 if (LL16) {
                     const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)iy[0] * A[c].ll_stride;
-                    const uint32_t le = *(const uint32_t *)(lrow + col[0]);
-                    Lr[c][0] = lo16(le); Lr[c][2] = hi16(le);
+                    Lr[c][0] = *(const uint32_t *)(lrow + col[0]);
                 } else {
                     const uint2 le = *(const uint2 *)(llp[c] + (size_t)iy[0] * A[c].ll_stride + col[0]);
                     Lr[c][0] = le.x; Lr[c][2] = le.y;
                 }
-                Lr[c][1] = lo16(lo); Lr[c][3] = hi16(lo);
-                Hr[c][0] = lo16(he); Hr[c][1] = lo16(ho); Hr[c][2] = hi16(he); Hr[c][3] = hi16(ho);
             }
         } else if (FAST || interior) {
 #pragma unroll
@@ -252,7 +255,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 
     /* output columns of this lane */
     const int xa = pe0 - g.mh;
-    const int x_hi = min(x0 + STREAM_TW, g.lh);
+    const int x_hi = min(x0 + tw, g.lh);
     int ia = 0, ib = 0;                                   /* valid positions of the quadruple: [ia, ib) */
     if (lane >= 1 && lane <= 62) {
         ia = max(0, x0 - xa);
@@ -429,6 +432,14 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         uint32_t r_odd[NC][4], r_even[NC][4];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
+            if (C16) {                                         /* the dwords of load_rows -> samples */
+                auto lo16 = [](uint32_t v) { return (uint32_t)(int32_t)(int16_t)(v & 0xFFFFu); };
+                auto hi16 = [](uint32_t v) { return (uint32_t)((int32_t)v >> 16); };
+                const uint32_t lo = Lc[c][1], he = Hc[c][0], ho = Hc[c][1];
+                if (LL16) { const uint32_t le = Lc[c][0]; Lc[c][0] = lo16(le); Lc[c][2] = hi16(le); }
+                Lc[c][1] = lo16(lo); Lc[c][3] = hi16(lo);
+                Hc[c][0] = lo16(he); Hc[c][1] = lo16(ho); Hc[c][2] = hi16(he); Hc[c][3] = hi16(ho);
+            }
             stream_hlift<TYPE>(Lc[c], mirror_l, mirror_r);
             stream_hlift<TYPE>(Hc[c], mirror_l, mirror_r);
 #pragma unroll
@@ -462,9 +473,12 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
      * with the arithmetic they were meant to overlap) */
     auto pin = [&](uint32_t (&Lr)[NC][4], uint32_t (&Hr)[NC][4]) {
 #pragma unroll
-        for (int c = 0; c < NC; c++)
-            asm volatile("" : "+v"(Lr[c][0]), "+v"(Lr[c][1]), "+v"(Lr[c][2]), "+v"(Lr[c][3]),
-                              "+v"(Hr[c][0]), "+v"(Hr[c][1]), "+v"(Hr[c][2]), "+v"(Hr[c][3]) : : "memory");
+        for (int c = 0; c < NC; c++) {
+            if (C16 && LL16) asm volatile("" : "+v"(Lr[c][0]), "+v"(Lr[c][1]), "+v"(Hr[c][0]), "+v"(Hr[c][1]) : : "memory");
+            else if (C16) asm volatile("" : "+v"(Lr[c][0]), "+v"(Lr[c][1]), "+v"(Lr[c][2]), "+v"(Hr[c][0]), "+v"(Hr[c][1]) : : "memory");
+            else asm volatile("" : "+v"(Lr[c][0]), "+v"(Lr[c][1]), "+v"(Lr[c][2]), "+v"(Lr[c][3]),
+                                   "+v"(Hr[c][0]), "+v"(Hr[c][1]), "+v"(Hr[c][2]), "+v"(Hr[c][3]) : : "memory");
+        }
         /* the registers of the last step's store data stay allocated until the next loads are
          * out: rewriting them earlier costs a wait for those stores (and, vmcnt being in order,
          * for every load issued before them) */
@@ -474,6 +488,29 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
             asm volatile("" : : "v"(ak[0]), "v"(ak[1]));
         }
     };
+    if (NC == 1) {
+        /* One component per wave: a step's loads are 1 KB per wave, and 8 waves per SIMD with one step in flight each
+         * are 8 MB on the whole chip -- at ~1.6 us of loaded HBM latency that caps the kernel near 5 TB/s, which is
+         * where the plain levels sat (4.1-4.4 TB/s against 5.2 for the three-component final level and 5.4 for
+         * tools/microbench/strip_bw.hip, the same access pattern with every load of a strip in flight).  So: three
+         * buffers, loads two steps ahead. */
+        uint32_t LC[NC][4], HC[NC][4];
+        load_rows(s_first + 2 * dir, LB, HB);
+        for (int ye = s_first;; ye += 6 * dir) {
+            load_rows(ye + 4 * dir, LC, HC);
+            pin(LA, HA);
+            step(ye, LA, HA);
+            if (dir * (ye + 2 * dir - s_last) > 0) break;
+            load_rows(ye + 6 * dir, LA, HA);
+            pin(LB, HB);
+            step(ye + 2 * dir, LB, HB);
+            if (dir * (ye + 4 * dir - s_last) > 0) break;
+            load_rows(ye + 8 * dir, LB, HB);
+            pin(LC, HC);
+            step(ye + 4 * dir, LC, HC);
+            if (dir * (ye + 6 * dir - s_last) > 0) break;
+        }
+    } else
     for (int ye = s_first;; ye += 4 * dir) {
         load_rows(ye + 2 * dir, LB, HB);
         pin(LA, HA);
@@ -545,16 +582,16 @@ __host__ __device__ inline int stream_fast_outk(const PackTile &T, const DwtLeve
 template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0>
 __device__ __forceinline__ void
 idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
-                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int bx, int by)
+                 uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by)
 {
     static_assert(!C16 || FASTONLY, "16-bit sub-bands: FASTONLY launches only");
     if (FASTONLY) {
-        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16, OUTK>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16, OUTK>(A, ll_base, band_base, out_base, T, comp0, th, tw, bx, by);
     } else {                                               /* per-wave choice; all conditions are wave-uniform */
         bool fast = stream_fast_geom(A[0].g);
         if (FUSED) fast = fast && stream_fast_rgb24(*T, A[0].g, NC, comp0);
-        if (fast) idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
-        else idwt_stream_impl<TYPE, NC, FUSED, false>(A, ll_base, band_base, out_base, T, comp0, th, bx, by);
+        if (fast) idwt_stream_impl<TYPE, NC, FUSED, true>(A, ll_base, band_base, out_base, T, comp0, th, tw, bx, by);
+        else idwt_stream_impl<TYPE, NC, FUSED, false>(A, ll_base, band_base, out_base, T, comp0, th, tw, bx, by);
     }
 }
 
@@ -564,7 +601,7 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
  * table entry) order: column strips that share cache lines at their edges (a wave loads 512 bytes
  * per sub-band row of which 488 are its own, and 244-sample strips are not line-aligned) and row
  * strips that share HALO rows meet in the same L2 instead of fetching those lines once per XCD. */
-struct StreamGrid { int gx, gy, nstrips, per_xcd; };
+struct StreamGrid { int gx, gy, nstrips, per_xcd, tw; };
 __device__ __forceinline__ bool stream_strip(const StreamGrid &G, int &bx, int &by, int &bz)
 {
     const int b = blockIdx.x;
@@ -586,7 +623,7 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
     int bx, by, bz;
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
-    idwt_stream_body<TYPE, 1, false, FASTONLY, C16, LL16>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by);
+    idwt_stream_body<TYPE, 1, false, FASTONLY, C16, LL16>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by);
 }
 
 /* plain 5/3 level of a job with 16-bit sub-bands whose LL bands are 16-bit as well, in and out */
@@ -598,7 +635,7 @@ k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restr
     int bx, by, bz;
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
-    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16>(A, ll_base, band_base, out_base, nullptr, 0, th, bx, by, ovf, ovf_bits);
+    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
@@ -613,7 +650,7 @@ k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__rest
     DwtTileArgs A[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) A[c] = F.a[c];
-    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16, OUTK>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, bx, by);
+    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16, OUTK>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, G.tw, bx, by);
 }
 
 }  // namespace htj2k

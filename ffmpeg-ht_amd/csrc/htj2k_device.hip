@@ -1165,10 +1165,28 @@ static int stream_strip_rows(int max_lh, int max_lv, int count)
     return cols * ((max_lv + 15) / 16) * count >= 2048 ? 16 : 8;
 }
 
-static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count)
+/* Output columns per wave.  out_bytes = bytes one output column takes in the row a strip stores (2 / 4: a 16- / 32-bit
+ * LL band; 3 / 6 / 1 / 2: rgb24 / rgb48 / 8- / 16-bit plane of the fused final level; 0: general path). */
+static int stream_strip_cols(int max_lh, int out_bytes)
+{
+    const char *e = getenv(out_bytes == 2 ? "HTJ2K_TW16" : out_bytes == 4 ? "HTJ2K_TW32" : "HTJ2K_TWF");
+    if (e && atoi(e) >= 64 && atoi(e) <= STREAM_TW) return atoi(e) & ~3;
+    /* 224 columns are 448 / 896 / 1344 bytes of 16-bit / 32-bit / rgb48 output: whole 64-byte pieces, so that two
+     * neighbouring strips never write into the same piece of a line (244 columns end mid-line, and half of a 16-bit
+     * strip's lines are shared with a neighbour).  It idles 5 more lanes of 64 and adds a strip per 11, which only pays
+     * once a row has several strips: measured per level on C2 / C3 / C4, 16-bit rows from 1920
+     * columns (288 -> 265 us at 1920, 67 -> 73 at 960), 32-bit rows from 960 (237 -> 221 us at 1920, 76 -> 66 at 960).
+     * rgb24 rows (732 bytes per strip, never a multiple of 64 below 256 columns) keep the full width. */
+    if (out_bytes == 2) return max_lh >= 1920 ? 224 : STREAM_TW;
+    if (out_bytes == 4 || out_bytes == 6) return max_lh >= 960 ? 224 : STREAM_TW;
+    return STREAM_TW;
+}
+
+static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count, int tw = STREAM_TW)
 {
     StreamGrid G;
-    G.gx = (max_lh + STREAM_TW - 1) / STREAM_TW;
+    G.tw = tw;
+    G.gx = (max_lh + tw - 1) / tw;
     G.gy = (max_lv + th - 1) / th;
     G.nstrips = G.gx * G.gy * count;
     G.per_xcd = (G.nstrips + 7) / 8;
@@ -1181,7 +1199,7 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
 {
     if (mode >= 3 && min_l >= 2) {
         const int th = stream_strip_rows(max_lh, max_lv, count);
-        const StreamGrid G = stream_grid(max_lh, max_lv, th, count);
+        const StreamGrid G = stream_grid(max_lh, max_lv, th, count, stream_strip_cols(max_lh, all_fast ? 4 : 0));
         dim3 g(8 * G.per_xcd);
         if (TYPE == J2K_DWT53 && coef16 == 2) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
         else if (TYPE == J2K_DWT53 && coef16 == 1) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
@@ -1202,7 +1220,7 @@ static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, 
 {
     if (TYPE == J2K_DWT53 && j->ll16_run && c->idwt_mode >= 3 && L.min_l >= 2) {    /* 16-bit sub-bands and LL bands, in and out */
         const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
-        const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count);
+        const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, stream_strip_cols(L.max_lh, 2));
         hipLaunchKernelGGL(k_idwt_stream_ll16, dim3(8 * G.per_xcd), dim3(64), 0, j->stream,
                            (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
                            (int *)j->d_status.p + j->blocks.size(), c->ll16_test_bits);
@@ -1217,7 +1235,8 @@ template <int TYPE>
 static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll)
 {
     const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
-    const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count);
+    const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count,
+                                     stream_strip_cols(L.max_lh, L.outk == 0 ? 3 : L.outk == 1 ? 6 : L.outk == 2 ? 1 : L.outk == 3 ? 2 : 0));
     dim3 g(8 * G.per_xcd);
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
