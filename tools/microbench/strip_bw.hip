@@ -56,6 +56,67 @@ template <int CPL> void run(const char *name, int W, int H, int nplanes, int th,
     const double bytes = (double)W * H * nplanes * 2 * 2;   // every sample read once and written once, 2 B each
     printf("%-10s W %5d H %5d planes %4d th %3d stride %5d grid %7d: %8.1f us  %6.2f TB/s\n", name, W, H, nplanes, th, BS, grid, ms * 1e3, bytes / ms / 1e9);
 }
+// The shipped geometry: a wave covers columns x0 - 4 .. x0 + 251 (4 per lane), lanes 0 and 63 only feed their neighbours'
+// lifting, lanes 1 .. TW / 4 store.  TW = 256: what a wave that fetched its two halo samples separately could do -- every
+// lane stores, strips start on line boundaries.  RGB: three 16-bit components in, 12 bytes of rgb24 per lane and row out.
+template <bool RGB>
+__global__ void __launch_bounds__(64) k_halo(const uint16_t *__restrict__ band, const uint16_t *__restrict__ ll, uint8_t *__restrict__ out,
+                                             int W, int H, int th, int nplanes, int TW)
+{
+    const int strips_x = (W + TW - 1) / TW, strips_y = (H + th - 1) / th;
+    int id = blockIdx.x;
+    const int bx = id % strips_x; id /= strips_x;
+    const int by = id % strips_y; const int pl = id / strips_y;
+    if (pl >= nplanes) return;
+    const int halo = TW == 256 ? 0 : 4;
+    const int x0 = bx * TW, x = x0 - halo + (int)threadIdx.x * 4;
+    const int xc = min(max(x, 0), W - 4);
+    const bool st = x >= x0 && x + 4 <= min(x0 + TW, W);
+    const size_t plane = (size_t)W * H;
+    const int hw = W / 2, hh = H / 2;
+    const int y0 = by * th, y1 = min(y0 + th, H);
+    constexpr int NC = RGB ? 3 : 1;
+    uint32_t acc = 0;
+    for (int y = y0; y < y1; y += 2) {
+        const int r = y >> 1;
+        uint32_t a[NC], h[NC], c[NC], d[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const uint16_t *b = band + (pl * NC + k) * plane, *l = ll + (pl * NC + k) * (plane / 4);
+            a[k] = *(const uint32_t *)(l + (size_t)r * hw + xc / 2);
+            h[k] = *(const uint32_t *)(b + (size_t)r * W + hw + xc / 2);
+            c[k] = *(const uint32_t *)(b + (size_t)(hh + r) * W + xc / 2);
+            d[k] = *(const uint32_t *)(b + (size_t)(hh + r) * W + hw + xc / 2);
+        }
+        if (RGB) {
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+            u32x3 s0, s1;
+            s0.x = a[0] + acc; s0.y = h[1]; s0.z = a[2]; s1.x = c[0]; s1.y = d[1] + acc; s1.z = c[2] ^ d[0] ^ h[0] ^ h[2] ^ a[1] ^ c[1] ^ d[2];
+            acc += a[0] ^ d[2];
+            uint8_t *o = out + (size_t)pl * plane * 3;
+            if (st) { *(u32x3_a4 *)(o + ((size_t)y * W + x) * 3) = s0; *(u32x3_a4 *)(o + ((size_t)(y + 1) * W + x) * 3) = s1; }
+        } else {
+            uint16_t *o = (uint16_t *)out + pl * plane;
+            const uint2 s0 = make_uint2(a[0] + acc, h[0]), s1 = make_uint2(c[0], d[0] + acc);
+            acc += a[0] ^ d[0];
+            if (st) { *(uint2 *)(o + (size_t)y * W + x) = s0; *(uint2 *)(o + (size_t)(y + 1) * W + x) = s1; }
+        }
+    }
+}
+template <bool RGB> void run_halo(int W, int H, int nplanes, int th, int TW, uint16_t *band, uint16_t *ll, uint16_t *out)
+{
+    const int grid = ((W + TW - 1) / TW) * ((H + th - 1) / th) * nplanes;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_halo<RGB>, dim3(grid), dim3(64), 0, 0, band, ll, (uint8_t *)out, W, H, th, nplanes, TW);
+    (void)hipEventRecord(e0);
+    const int R = 10;
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL(k_halo<RGB>, dim3(grid), dim3(64), 0, 0, band, ll, (uint8_t *)out, W, H, th, nplanes, TW);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= R;
+    const double bytes = (double)W * H * nplanes * (RGB ? 3 * 2 + 3 : 2 + 2);
+    printf("%-6s W %5d H %5d planes %4d th %3d TW %3d grid %7d: %8.1f us  %6.2f TB/s\n", RGB ? "rgb24" : "ll16", W, H, nplanes, th, TW, grid, ms * 1e3, bytes / ms / 1e9);
+}
 int main()
 {
     const size_t maxs = (size_t)3840 * 2160 * 144;
@@ -74,6 +135,9 @@ int main()
     run<8>("cpl8", 3840, 2160, 144, 16, band, ll, out);
     run<4>("cpl4", 960, 540, 144, 16, band, ll, out);
     run<8>("cpl8", 960, 540, 144, 16, band, ll, out);
+    for (int tw : { 244, 224, 256 }) run_halo<false>(1920, 1080, 144, 16, tw, band, ll, out);
+    for (int tw : { 244, 224, 256 }) run_halo<false>(960, 540, 144, 16, tw, band, ll, out);
+    for (int tw : { 244, 224, 192, 256 }) run_halo<true>(3840, 2160, 48, 16, tw, band, ll, out);
     hipMemcpy(out, band, maxs * 2, hipMemcpyDeviceToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
