@@ -1,8 +1,8 @@
-"""gpurun_out/prof_r01/ (written by tools/prof_r01.sh on the GPU box) -> profiles/r01_*: the summaries the
+"""gpurun_out/prof_<tag>/ (written by tools/prof_round.sh <tag> on the GPU box) -> profiles/<tag>_*: the summaries the
 round's numbers come from.  Usage: python tools/make_profiles.py [round-tag]"""
 import collections, csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -53,7 +53,7 @@ idwt = [r for r in rows if "idwt" in r[0]]
 per_step = sum(r[5] * r[2] for r in idwt) / max(1, min(r[2] for r in idwt if "pack" in r[0]) if any("pack" in r[0] for r in idwt) else 1)
 launches_per_step = sum(r[2] for r in idwt) / max(1, [r[2] for r in idwt if "pack" in r[0]][0])
 cfg = json.loads(bench_line)["config"]
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 10 --warmup 2 "
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 10 --warmup 2 --jobs 1 "
                      "--no-cpu-baseline --no-e2e`, hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving, calibrated in "
                      + tag + "_membw_calibration.txt)",
            "frames_per_step": cfg["frames_per_step"], "idwt_launches_per_step": launches_per_step,
@@ -63,3 +63,33 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
           open(os.path.join(dst, tag + "_idwt_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, tag + "_pmc_hbm.csv")).read())
 print(open(os.path.join(dst, tag + "_idwt_traffic.json")).read())
+
+
+# 5. average duration per (kernel, grid size) of the trace: tells the IDWT levels apart (the stats file has one row per kernel name)
+acc = collections.OrderedDict()
+for r in csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_trace.csv"))):
+    n = r["Kernel_Name"].split("(")[0]
+    if "rocclr" in n or "fill" in n.lower(): continue
+    a = acc.setdefault((n, r["Grid_Size_X"]), [0, 0.0])
+    a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+with open(os.path.join(dst, tag + "_bench_kernels_by_grid.csv"), "w") as o:
+    o.write("kernel,grid_size_x,dispatches,avg_us\n")
+    for (n, g), (c, t) in acc.items(): o.write('"%s",%s,%d,%.1f\n' % (n, g, c, t / c))
+
+# 6. the other configurations (tools/gpu_configs.py): stage times, per-kernel stats, HBM bytes of their IDWT launches
+if os.path.exists(os.path.join(src, "configs.json")):
+    shutil.copy(os.path.join(src, "configs.json"), os.path.join(dst, tag + "_configs.json"))
+    shutil.copy(os.path.join(src, "configs.log"), os.path.join(dst, tag + "_configs.txt"))
+if os.path.exists(os.path.join(src, "cfg_trace", "cfg_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "cfg_trace", "cfg_kernel_stats.csv"), os.path.join(dst, tag + "_configs_C3_C4_kernel_stats.csv"))
+    f2 = pmc(os.path.join(src, "cfg_fetch", "cfg_counter_collection.csv"))
+    w2 = pmc(os.path.join(src, "cfg_write", "cfg_counter_collection.csv"))
+    with open(os.path.join(dst, tag + "_configs_C3_C4_pmc_hbm.csv"), "w") as o:
+        o.write("kernel,grid_size,dispatches,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean,hbm_MB_per_dispatch(2*FETCH+WRITE)\n")
+        for k in f2:
+            if "rocclr" in k[0]: continue
+            n, f = f2[k]; w = w2.get(k, (0, 0.0))[1]
+            o.write('"%s",%s,%d,%.1f,%.1f,%.1f\n' % (k[0], k[1], n, f, w, (2 * f + w) * 1024 / 1e6))
+if os.path.exists(os.path.join(src, "ht_sq.csv")):
+    shutil.copy(os.path.join(src, "ht_sq.csv"), os.path.join(dst, tag + "_ht_sq.csv"))
+print(sorted(x for x in os.listdir(dst) if x.startswith(tag)))
