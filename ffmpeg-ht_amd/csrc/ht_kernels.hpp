@@ -1552,14 +1552,16 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
     uint32_t *vst = vstage + lane * VPITCH;
     uint32_t *ost = ostage + lane * OPITCH;
-    /* VLC words: a ring of 16 per lane in LDS (vst[w & 15] = stream word w).  Every second pass a lane whose ring holds fewer than 8
-     * words beyond its position asks for the next 4; they are written to the ring two passes later.  Two passes take
-     * at most 76 bits, so a lane that did not ask still has 5 words at the next check, one that did has 6 (a pass
-     * reads 3 from a position at most 2 words further); the 4 slots written are at least 5 words behind the position.
-     * Every stream byte is fetched once: 24-dword windows re-requested every 8 passes fetched each byte ~7 times,
+    /* VLC words: a ring of 16 per lane in LDS (vst[w & 15] = stream word w).  Every second pass a lane whose ring holds
+     * fewer than 8 words beyond its position asks for the next 8 (32 bytes: a quarter of a line -- with 16 the line had
+     * left the L2 again before the lane came back for its next piece, and FETCH_SIZE was six times the stream); they are
+     * written to the ring two passes later.  Two passes take at most 76 bits, so a lane that did not ask still has 5
+     * words at the next check (a pass reads 3 from a position at most 2 words further); the 8 slots written are at
+     * least one word behind the position (it asked with fewer than 8 ahead), and at most 15 words are ever ahead.
+     * Every stream byte is requested once: 24-dword windows re-requested every 8 passes asked for each byte ~7 times,
      * and L2 requests, not arithmetic, bounded this kernel. */
-    uint4 nxv = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t hw = 16, pw = 0;                            /* words requested so far / word index of nxv */
+    uint4 nxv = make_uint4(0u, 0u, 0u, 0u), nxw = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t hw = 16, pw = 0;                            /* words requested so far / word index of nxv (nxw: the four after it) */
     bool pend = false;
     /* MEL (jpeg2000htdec.c:462-495): decoded symbols are buffered, LSB = next symbol; the
      * adaptive run-length state machine only runs in a rarely taken refill path that decodes
@@ -1617,12 +1619,15 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (pend) {
                 uint32_t *r = vst + (pw & 15);
                 r[0] = nxv.x; r[1] = nxv.y; r[2] = nxv.z; r[3] = nxv.w;
+                r = vst + ((pw + 4) & 15);
+                r[0] = nxw.x; r[1] = nxw.y; r[2] = nxw.z; r[3] = nxw.w;
             }
             pend = (int)(hw - (vpos >> 5)) < 8;
             if (pend) {
                 __builtin_memcpy(&nxv, vsrc + hw, 16);
+                __builtin_memcpy(&nxw, vsrc + hw + 4, 16);
                 pw = hw;
-                hw += 4;
+                hw += 8;
             }
             if ((t & (CAD - 1)) == 0 && t) flush(t / CAD - 1);   /* behind the load: nothing waits for these stores */
         }
