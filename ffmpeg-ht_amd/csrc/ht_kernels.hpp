@@ -244,7 +244,7 @@ __device__ __forceinline__ uint32_t ht_dpp_right(uint32_t v)       /* lane i <- 
 /* MagSgn bytes -> plain LSB-first bit array in LDS (jpeg2000htdec.c:207-221): a byte that follows
  * 0xFF advances the stream by 7 bits but is ORed in whole.  Four bytes per lane and pass: the
  * lane's bytes are merged into one chunk of 28..32 stream bits, a wave prefix sum of the chunk
- * lengths gives its bit offset, two ds_or place it.  D is 16-byte aligned (j2k_parse.c lays the
+ * lengths gives its bit offset, two ds_or place it.  D is 16-byte aligned (j2k_plan.c lays the
  * block data out that way); ms[] must be zero up to the word after the last stream bit.
  * Returns the number of stream bits. */
 /* one pass over 64 dwords: `dw` is dword w0 + lane of the stream (anything where the stream has ended) */

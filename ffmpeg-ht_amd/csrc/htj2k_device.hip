@@ -1827,7 +1827,7 @@ extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int 
 /* HT block decoder alone: decode `n` codeblocks given as a descriptor table + byte pool into
  * a sample buffer (unit parity against ff_jpeg2000_decode_htj2k + dequantisation) */
 /* decode_cblk() + dequantisation on a caller-built table of Part-1 blocks: every descriptor carries J2K_BLK_PART1 and
- * its bytes are laid out as j2k_parse.c does it (j2k_plan.h: segments, 0xFF 0xFF terminators, J2kPart1Trailer) */
+ * its bytes are laid out as j2k_plan.c does it (j2k_plan.h: segments, 0xFF 0xFF terminators, J2kPart1Trailer) */
 /* A caller-built descriptor (the unit entry points below) gets the guarantees the job path has from the host parser:
  * the block is at most 4096 samples and 1024 in either direction (jpeg2000htdec.c:1230-1232, what the kernels' LDS and
  * quad-symbol sizing assume), its window lies inside the coefficient buffer, the numbers the kernels shift by are in
@@ -1918,7 +1918,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
 {
     if (!c || !blocks_in || nblocks <= 0 || !bytes_in || !coef) return HTJ2K_ERR_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    /* the kernels want the layout j2k_parse.c produces: every block's bytes at a 16-byte aligned
+    /* the kernels want the layout j2k_plan.c produces: every block's bytes at a 16-byte aligned
      * offset, J2K_BLOCK_PAD bytes behind them and 16 in front of the first: re-pack the caller's pool */
     std::vector<J2kBlock> blk((const J2kBlock *)blocks_in, (const J2kBlock *)blocks_in + nblocks);
     std::vector<uint8_t> pool(16, 0);

@@ -7,7 +7,7 @@
  *
  * It is deliberately independent of the decoder sources in this repo: geometry is
  * derived from T.800 Annex B formulas here, and from the reference's
- * ff_jpeg2000_init_component() restatement in j2k_parse.c, so a disagreement shows
+ * ff_jpeg2000_init_component() restatement in the decoders (csrc/j2k_tier2.c, oracle/j2k_oracle_parse.c), so a disagreement shows
  * up as a failed decode.  Streams are additionally decoded by OpenJPEG (Pillow) in
  * the tests as a third opinion.
  *
@@ -1126,7 +1126,7 @@ static void band_quant(const htj2k_enc_params *P, int c, int r, int b, int NL, i
     }
 }
 
-/* the decoder's f_stepsize for this band (jpeg2000.c:214-272 as restated in j2k_parse.c;
+/* the decoder's f_stepsize for this band (jpeg2000.c:214-272 as restated in csrc/j2k_tier2.c:band_step;
  * duplicated here on purpose so the factory stays independent of the product parser) */
 static float band_fstep(const htj2k_enc_params *P, int c, int r, int b, int NL, int expn, int mant)
 {
