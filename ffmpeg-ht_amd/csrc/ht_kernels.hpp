@@ -572,6 +572,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const bool fast_blk = !ok || (pLSB >= dshift && pLSB >= 1 && pLSB <= 30 && maxbp <= 16);
     if (__ballot(!fast_blk) == 0) {
         const uint32_t up = (uint32_t)(pLSB - dshift) & 31u, hb = (halfbit & 0x7FFFFFFFu) >> (dshift & 31);
+        const uint32_t up2 = (up & 15u) * 0x00010001u, hb2 = (hb & 0xFFFFu) * 0x00010001u;
         /* SIMPLE (wave-uniform): both blocks have the same, even, height -- nearly every wave, the block table is sorted
          * by size.  Then which lanes store is fixed for the whole loop: lanes outside their block aim at the scratch
          * line from the start (stride 0), and every row issues exactly two stores behind the prefetch of the next row's
@@ -621,17 +622,23 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             lo = __builtin_amdgcn_alignbit(hi, lo, n2);
             uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, n3);
             v0 += (X1 & 1) << n0; v1 += ((X1 >> 8) & 1) << n1; v2 += ((X1 >> 16) & 1) << n2; v3 += (X1 >> 24) << n3;
-            const int s0m = -(int)(R & 1), s1m = -(int)((R >> 8) & 1), s2m = -(int)((R >> 16) & 1), s3m = -(int)(R >> 24);
-            E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
-            E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
-            auto sample = [&](uint32_t v, int sm) -> uint32_t {              /* mu (:407-427) -> dequantization_int */
-                const int r = (int)((((v >> 1) + 1u) << up) | hb);
-                const int sg = -(int)(v & 1);
-                return (uint32_t)(((r ^ sg) - sg) & sm);
+            /* bottom-left and bottom-right feed the next row */
+            E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)-(int)((R >> 8) & 1);
+            E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)-(int)(R >> 24);
+            /* mu (:407-427) -> dequantization_int, two samples per instruction: v < 2^16 (at most 16 magnitude bits, the
+             * known MSB only where the bound took one away), the result < 2^M_b <= 2^15 -- and whatever a block that is
+             * about to be rejected overflows stays inside its own half */
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            auto samples = [&](uint32_t va, uint32_t vb, uint32_t sig) -> uint32_t {   /* sig: bit 0 / 16 = sample a / b is significant */
+                const u16x2 one = { 1, 1 };
+                const u16x2 P = __builtin_bit_cast(u16x2, va | (vb << 16));
+                u16x2 r = ((P >> one) + one) << __builtin_bit_cast(u16x2, up2);
+                r |= __builtin_bit_cast(u16x2, hb2);
+                const u16x2 sg = (u16x2){ 0, 0 } - (P & one);
+                r = (r ^ sg) - sg;
+                return __builtin_bit_cast(uint32_t, r) & __builtin_bit_cast(uint32_t, (u16x2)((u16x2){ 0, 0 } - __builtin_bit_cast(u16x2, sig)));
             };
-            /* low halves of two samples into one dword */
-            const uint32_t top = __builtin_amdgcn_perm(sample(v2, s2m), sample(v0, s0m), 0x05040100u);
-            const uint32_t bot = __builtin_amdgcn_perm(sample(v3, s3m), sample(v1, s1m), 0x05040100u);
+            const uint32_t top = samples(v0, v2, R & 0x00010001u), bot = samples(v1, v3, (R >> 8) & 0x00010001u);
             if (SIMPLE) {
                 *(uint32_t *)pt = top;
                 *(uint32_t *)(pt + st) = bot;
