@@ -719,6 +719,237 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     }
 }
 
+/* ================================================================== k_ht_decode_multi
+ * k_ht_decode_pair's arrangement -- a LANE PER QUAD, several codeblocks per wavefront -- for the jobs that keep 32-bit
+ * sub-bands: NB = 2 blocks of up to 64 columns (lanes 0-31 / 32-63) or NB = 4 blocks of up to 32 columns (16 lanes
+ * each; cb = 32 streams left half the lanes of the column-per-lane kernel idle), any of the three dequantisers
+ * (jpeg2000dec.c:2098-2181), any width and height.  For jobs whose HT blocks are all cleanup-only, at most 64 columns
+ * wide, without ROI shift and of one transform (htj2k_device.hip: multi_ok); everything else stays with
+ * k_ht_decode<true>.  Same arithmetic as ht_magsgn_rows_narrow (jpeg2000htdec.c:855-885 kappa, :395-427 mu / E). */
+template <int LPB>
+__device__ __forceinline__ uint32_t seg_incl_scan_u32(uint32_t v)    /* inclusive prefix sum inside each run of LPB lanes */
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    if (LPB == 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      /* row_bcast15 into rows 1 and 3 */
+    return (uint32_t)x;
+}
+template <int LPB>
+__device__ __forceinline__ uint32_t seg_last(uint32_t v)             /* the value of the last lane of this lane's run */
+{
+    /* ds_swizzle, bit mode: lane' = (lane & and) | or inside each half of the wave */
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, LPB == 32 ? (31 << 5) : (0x10 | (15 << 5)));
+}
+
+template <int NB, int TRANSFORM>
+__global__ void __launch_bounds__(64)
+k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+                  uint32_t *__restrict__ coef, int *__restrict__ status, uint32_t ms_words,
+                  const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink)
+{
+    constexpr int LPB = 64 / NB, PF = 16 / NB;               /* lanes per block; 256-byte pieces of a block's bytes requested up front */
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t *ms_all = (uint32_t *)smem;                     /* [NB][ms_words + 4] */
+    const int lane = threadIdx.x, seg = lane / LPB, q = lane % LPB;
+    const uint32_t mspitch = ms_words + 4;
+    bool ok_s[NB];
+    uint32_t lastwi_s[NB], Pcup_s[NB];
+    const uint32_t *Dw_s[NB];
+    uint32_t pv[NB][PF];
+
+    /* ---- per block, whole wave: checks, zero-fill of blocks without passes; the MagSgn bytes of all blocks are
+     * requested before any is worked on ---- */
+#pragma unroll
+    for (int hb = 0; hb < NB; hb++) {
+        ok_s[hb] = false; lastwi_s[hb] = 0; Pcup_s[hb] = 0; Dw_s[hb] = nullptr;
+#pragma unroll
+        for (int jx = 0; jx < PF; jx++) pv[hb][jx] = 0;
+        const int bidx = NB * (int)blockIdx.x + hb;
+        if (bidx >= nblocks) continue;
+        const J2kBlock b = blocks[bidx];
+        uint32_t *dst = coef + b.plane_off;
+        if (b.npasses == 0) {
+            ht_zero_window(dst, b.w, b.h, b.stride, lane);
+            continue;
+        }
+        const int rem = b.npasses % 3, num_plhd = rem ? b.npasses - rem : b.npasses - 3;
+        const int S_blk = (num_plhd / 3 + b.zbp) & 0xFF, maxbp = S_blk + 1;
+        const uint32_t Lcup = b.lcup;
+        const uint8_t *D = bytes + b.data_off;
+        Dw_s[hb] = (const uint32_t *)D;
+#pragma unroll
+        for (int jx = 0; jx < PF; jx++) {                    /* before Scup says where the MagSgn bytes end: Pcup <= Lcup */
+            const uint32_t wi = 64 * jx + lane;
+            if (wi * 4 < Lcup) pv[hb][jx] = Dw_s[hb][wi];
+        }
+        int err = 0;
+        uint32_t Scup = 0, Pcup = 0;
+        if (Lcup < 2) err = HT_ERR_INVALID;
+        if (!err) {
+            Scup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F)));
+            if (Scup < 2 || Scup > Lcup || Scup > 4079) err = HT_ERR_INVALID;
+            Pcup = Lcup - Scup;
+        }
+        if (!err && maxbp >= 32) err = HT_ERR_INVALID;
+        if (!err && ((Pcup * 8 + 31) / 32 + 3 > ms_words || ((b.w + 1) >> 1) > LPB)) err = HT_ERR_INVALID;
+        if (err) {
+            ht_zero_window(dst, b.w, b.h, b.stride, lane);
+            if (lane == 0) status[bidx] = err;
+            continue;
+        }
+        ok_s[hb] = true;
+        Pcup_s[hb] = Pcup;
+    }
+    bool any_ok = false;
+#pragma unroll
+    for (int hb = 0; hb < NB; hb++) {
+        if (!ok_s[hb]) continue;
+        any_ok = true;
+        const uint32_t Pcup = Pcup_s[hb];
+        uint32_t *ms = ms_all + hb * mspitch;
+        const uint32_t nms = (Pcup * 8 + 31) / 32 + 2;
+        for (uint32_t i = lane; i <= nms + 1; i += 64) ms[i] = 0;
+        __syncthreads();
+        uint32_t ms_total = 0, carry = 0;
+#pragma unroll
+        for (int jx = 0; jx < PF; jx++)
+            if (256u * jx < Pcup) ht_unstuff_magsgn_step(pv[hb][jx], 64 * jx, Pcup, ms, lane, ms_total, carry);
+        for (uint32_t w0 = 64 * PF; w0 * 4 < Pcup; w0 += 64) {
+            const uint32_t wi = w0 + lane;
+            ht_unstuff_magsgn_step(wi * 4 < Pcup ? Dw_s[hb][wi] : 0u, w0, Pcup, ms, lane, ms_total, carry);
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i <= nms + 1; i += 64) {     /* past the end the MagSgn stream is all ones (:207-221) */
+            if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
+            else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
+        }
+        lastwi_s[hb] = nms - 2;                              /* words last_wi .. last_wi + 3 exist and are ones past the end */
+    }
+    __syncthreads();
+    if (!any_ok) return;
+
+    /* ---- all blocks in lockstep: this lane's block ---- */
+    const int bi = min(NB * (int)blockIdx.x + seg, nblocks - 1);
+    const J2kBlock b = blocks[bi];
+    bool ok = false;
+    uint32_t last_wi = 0;
+#pragma unroll
+    for (int hb = 0; hb < NB; hb++)
+        if (seg == hb) { ok = ok_s[hb]; last_wi = lastwi_s[hb]; }
+    const int w = b.w, h = b.h, stride = b.stride, M_b = b.M_b;
+    const int qw = (w + 1) >> 1, qh = ok ? (h + 1) >> 1 : 0;
+    const int rem = b.npasses % 3, num_plhd = rem ? b.npasses - rem : b.npasses - 3;
+    const int S_blk = (num_plhd / 3 + b.zbp) & 0xFF;
+    const int pLSB = (30 - S_blk) & 0xFF, maxbp = S_blk + 1, dshift = 31 - M_b;
+    const uint32_t halfbit = 1u << ((pLSB - 1) & 31);
+    float fscale = b.f_step;
+    fscale /= (float)(1 << (31 - b.M_b));                    /* jpeg2000dec.c:2104-2106 */
+    const int i_step = b.i_step;
+    const uint32_t *ms = ms_all + seg * mspitch;
+    const bool act = ok && q < qw;
+    const bool c2 = 2 * q + 1 < w;                           /* the quad's right column is inside the block */
+    const int qwp = (int)ht_qsym_pitch((uint32_t)w);
+    const ht_sym_t *qp = qsym + qoff[bi] + q;
+    uint32_t *prow = coef + b.plane_off + 2 * q;             /* this quad's two columns, row 2 * row */
+    int rows = 0;
+#pragma unroll
+    for (int hb = 0; hb < NB; hb++) rows = max(rows, __builtin_amdgcn_readlane(qh, hb * LPB));
+    /* odd widths: the last quad of a row has one column -- such waves store dwords, the others pairs */
+    const bool pairs = __ballot(act && !c2) == 0;
+    uint32_t qi_next = (act && qh > 0) ? *qp : 0u;
+    uint32_t E1p = 0, E3p = 0, ms_pos = 0;
+    int err = 0;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+    for (int row = 0; row < rows; row++) {
+        const bool arow = act && row < qh;
+        const uint32_t qi = qi_next;
+        qp += qwp;
+        qi_next = (act && row + 1 < qh) ? *qp : 0u;
+        /* field n of the symbol -> bits 0-1 of byte n; R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
+        const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);
+        const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1, uq = qi >> 8;
+        const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
+        int kappa = 1;
+        if (row > 0) {
+            uint32_t l = ht_dpp_left(E3p), r = ht_dpp_right(E1p);
+            l = q == 0 ? 0u : l;
+            r = q == LPB - 1 ? 0u : r;
+            const int me = (int)max(max(E1p, E3p), max(l, r));
+            kappa = (R & (R - 1)) ? max(me - 1, 1) : 1;
+        }
+        const uint32_t U = (uint32_t)kappa + uq;
+        if (arow && (int)U > maxbp) err = 1;
+        uint32_t Rs = R << 8;
+        asm("" : "+v"(Rs));
+        const uint32_t Rm = Rs - R;                                     /* 0xFF in the bytes of significant samples */
+        const uint32_t U4 = __builtin_amdgcn_perm(U, U, 0x00000000u);   /* U in all four bytes (U < 256) */
+        const uint32_t N = (U4 - K) & Rm;                               /* m_n = sigma_n * U - k_n, one byte each (:883-888) */
+        const uint32_t tot = __builtin_amdgcn_sad_u8(N, 0u, 0u);
+        const uint32_t incl = seg_incl_scan_u32<LPB>(tot);
+        const uint32_t p0 = ms_pos + incl - tot;
+        ms_pos += seg_last<LPB>(incl);
+        const uint32_t n0 = N & 0xFF, n1 = (N >> 8) & 0xFF, n2 = (N >> 16) & 0xFF, n3 = N >> 24;
+        const uint32_t p1 = p0 + n0, p2 = p1 + n1, p3 = p2 + n2;
+        auto cut = [&](uint32_t p, uint32_t n) -> uint32_t {            /* n <= 31 stream bits from position p */
+            const uint32_t i = min(p >> 5, last_wi + 2);
+            return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(ms[i + 1], ms[i], p), 0u, n);
+        };
+        uint32_t v0 = cut(p0, n0), v1 = cut(p1, n1), v2 = cut(p2, n2), v3 = cut(p3, n3);
+        v0 += (X1 & 1) << n0; v1 += ((X1 >> 8) & 1) << n1; v2 += ((X1 >> 16) & 1) << n2; v3 += (X1 >> 24) << n3;
+        const int s0m = -(int)(R & 1), s1m = -(int)((R >> 8) & 1), s2m = -(int)((R >> 16) & 1), s3m = -(int)(R >> 24);
+        E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
+        E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
+        auto sample = [&](uint32_t v, int sm) -> uint32_t {              /* mu (:407-427) -> dequantisation */
+            const uint32_t mu = (((((v >> 1) + 1u) << pLSB) | halfbit) | (v << 31)) & (uint32_t)sm;
+            if (TRANSFORM == J2K_DWT53) {
+                const int sg = (int)mu >> 31;
+                int r = (int)((mu & 0x7FFFFFFFu) >> dshift);
+                r = (r ^ sg) - sg;
+                if (i_step != 32768) {                                   /* block-uniform; reversible bands have step 1.0 */
+                    const long long a = (long long)r * i_step;
+                    r = (int)(a < 0 ? -((-a) >> 16) : (a >> 16));
+                }
+                return (uint32_t)r;
+            } else if (TRANSFORM == J2K_DWT97) {
+                /* (float)(-x) * s == -((float)x * s), and a zero magnitude never carries a sign */
+                return __float_as_uint((float)(mu & 0x7FFFFFFFu) * fscale) | (mu & 0x80000000u);
+            } else {
+                return ht_dequant(mu, TRANSFORM, M_b, 0, fscale, i_step);
+            }
+        };
+        const uint32_t o0 = sample(v0, s0m), o1 = sample(v1, s1m), o2 = sample(v2, s2m), o3 = sample(v3, s3m);
+        const bool two = 2 * row + 1 < h;
+        /* a fixed number of stores per row behind the prefetch of the next row's symbols (vmcnt(N) stays exact): lanes
+         * and rows with nothing to write aim at a scratch line */
+        if (pairs) {
+            u32x2 t, bt;
+            t.x = o0; t.y = o2; bt.x = o1; bt.y = o3;
+            *(u32x2_a4 *)(arow ? prow : sink) = t;
+            *(u32x2_a4 *)((arow && two) ? prow + stride : sink) = bt;
+        } else {
+            *(arow ? prow : sink) = o0;
+            *((arow && c2) ? prow + 1 : sink) = o2;
+            *((arow && two) ? prow + stride : sink) = o1;
+            *((arow && two && c2) ? prow + stride + 1 : sink) = o3;
+        }
+        prow += 2 * stride;
+    }
+    /* a block whose U ran past maxbp is rejected as a whole (:862-868): zero it, whole wave per block */
+#pragma unroll
+    for (int hb = 0; hb < NB; hb++) {
+        if (__ballot(err && seg == hb) == 0) continue;
+        const int bidx = NB * (int)blockIdx.x + hb;
+        const J2kBlock bb = blocks[bidx];
+        __syncthreads();
+        ht_zero_window(coef + bb.plane_off, bb.w, bb.h, bb.stride, lane);
+        if (lane == 0) status[bidx] = HT_ERR_INVALID;
+    }
+}
+
 /* EXTERNAL_VLC = false: the whole block in this kernel (stage 1 on lane 0).
  * EXTERNAL_VLC = true : stage 1 was done by k_ht_vlc (one LANE per codeblock, 64 serial decodes
  *                       per wavefront); the packed quad symbols come from `qsym` (qoff[b] is the

@@ -122,6 +122,7 @@ struct htj2k_ctx {
                                         * 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
+    int ht_multi = 1;                  /* 1: jobs with 32-bit sub-bands whose HT blocks qualify use k_ht_decode_multi (2 or 4 blocks per wave) */
     int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
     int ll16 = 1;                      /* 1: such jobs also keep the LL bands between the IDWT levels as int16_t (overflow is detected
                                         * on the device and the transform run again with 32-bit LL bands, job_settle) */
@@ -181,8 +182,11 @@ struct htj2k_job {
      * planes coded, reversible 5/3 with at least one level, all blocks HT cleanup-only, <= 64 columns, M_b <= 15,
      * step size 1, no ROI shift, all levels of fast geometry.  The sub-bands then travel as 2 bytes per sample. */
     bool pair_ok = false;              /* ... and k_ht_decode_pair's dword stores are aligned: even widths, strides, offsets */
+    int multi_nb = 0;                  /* k_ht_decode_multi: blocks per wave (2: blocks up to 64 columns, 4: up to 32), 0: not eligible */
+    int multi_t = 0;                   /* ... and the transform all HT blocks of the job share */
     bool coef16_ok = false;
     bool coef_is16 = false;            /* what the last HT stage run actually wrote */
+    int ht_bpw = 0;                    /* ... and with how many blocks per wave in the MagSgn kernel */
     bool ll16_run = false;             /* the last IDWT run wrote its LL bands as int16_t ... */
     bool ll16_checked = true;          /* ... and the overflow flag behind d_status has been looked at since */
     bool force_ll32 = false;           /* the re-run after an overflow */
@@ -333,6 +337,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "device_gather")) { c->device_gather = value ? 1 : 0; return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
     if (!strcmp(name, "bitexact")) { c->opts.bitexact = value; return 0; }
@@ -1083,6 +1088,24 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
             ok = !(b.w & 1) && !(b.stride & 1) && !(b.plane_off & 1);
         }
         j->pair_ok = ok;
+        /* k_ht_decode_multi: every block an HT block with the cleanup pass only, at most 64 columns, no ROI shift, one
+         * transform for all of them; four blocks per wave when none is wider than 32 columns */
+        bool mok = j->nht == (int)j->blocks.size() && j->reflist.empty() && !j->blocks.empty();
+        int maxw = 0;
+        const int t0 = mok ? (j->blocks[0].flags & 3) : 0;
+        for (size_t i = 0; mok && i < j->blocks.size(); i++) {
+            const J2kBlock &b = j->blocks[i];
+            mok = b.w <= 64 && b.roi_shift == 0 && (b.flags & 3) == t0;
+            if (mok && b.npasses) { const int rem = b.npasses % 3; mok = b.npasses - (rem ? b.npasses - rem : b.npasses - 3) == 1; }
+            if (b.w > maxw) maxw = b.w;
+        }
+        j->multi_nb = mok ? (maxw <= 32 ? 4 : 2) : 0;
+        j->multi_t = t0;
+        /* the kernel holds the un-stuffed MagSgn bits of all its blocks in LDS: with long segments (16-bit material: 10 KB
+         * per 64 x 64 block) two blocks per wave leave 2 waves per SIMD and the column-per-lane kernel is quicker
+         * (C4 gray16 1.50 -> 1.64 ms per 16 frames), with short ones it is not (int32 C2 2.93 -> 2.74, C3 2.15 -> 1.65) */
+        const size_t multi_lds_max = getenv("HTJ2K_MULTI_LDS") ? (size_t)atoi(getenv("HTJ2K_MULTI_LDS")) : 12 * 1024;
+        if (mok && (size_t)j->multi_nb * (j->lds_ext.ms_words + 4) * 4 > multi_lds_max) j->multi_nb = 0;
     }
     if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
@@ -1362,13 +1385,30 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                        (const uint8_t *)j->d_bytes.p, (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
                                        (uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
+                j->ht_bpw = (j->coef_is16 && j->pair_ok && c->ht_pair) ? 2 : (!j->coef_is16 && j->multi_nb && c->ht_multi) ? j->multi_nb : 1;
                 if (j->coef_is16 && j->pair_ok && c->ht_pair)
                     hipLaunchKernelGGL(k_ht_decode_pair, dim3((nblocks + 1) / 2), dim3(64), 2 * (j->lds_ext.ms_words + 4) * 4, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                        (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words,
                                        (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (uint32_t *)j->d_coef.p + j->nsamples + 32);
-                else
+                else if (!j->coef_is16 && j->multi_nb && c->ht_multi) {
+                    const int nb = j->multi_nb;
+                    const size_t lds = (size_t)nb * (j->lds_ext.ms_words + 4) * 4;
+#define HT_MULTI(NB_, T_) do { \
+                        if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode_multi<NB_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_ht_decode_multi<NB_, T_>), dim3((nblocks + NB_ - 1) / NB_), dim3(64), lds, j->stream, \
+                                           (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p, \
+                                           (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words, \
+                                           (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, \
+                                           (uint32_t *)j->d_coef.p + j->nsamples + 32); } while (0)
+                    if (nb == 4) {
+                        if (j->multi_t == J2K_DWT53) HT_MULTI(4, J2K_DWT53); else if (j->multi_t == J2K_DWT97) HT_MULTI(4, J2K_DWT97); else HT_MULTI(4, J2K_DWT97_INT);
+                    } else {
+                        if (j->multi_t == J2K_DWT53) HT_MULTI(2, J2K_DWT53); else if (j->multi_t == J2K_DWT97) HT_MULTI(2, J2K_DWT97); else HT_MULTI(2, J2K_DWT97_INT);
+                    }
+#undef HT_MULTI
+                } else
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_coef.p, (const uint16_t *)c->d_tables, (int *)j->d_status.p, j->lds_ext,
@@ -1376,6 +1416,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (uint32_t *)j->d_coef.p + j->nsamples + 32,
                                    (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p, j->coef_is16 ? 1 : 0);
             } else {
+                j->ht_bpw = 1;
                 if ((int)j->lds.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds.total));
                 hipLaunchKernelGGL(k_ht_decode<false>, dim3(nblocks), dim3(64), j->lds.total, j->stream,
@@ -1498,6 +1539,7 @@ extern "C" int htj2k_job_idwt_launches(htj2k_ctx *c, htj2k_job *j, float *ms, do
 
 /* 1 when the last htj2k_job_run kept the sub-bands as 16-bit samples between the block decoder and the IDWT */
 extern "C" int htj2k_job_coef16(const htj2k_job *j) { return j ? (j->coef_is16 ? 1 : 0) : HTJ2K_ERR_EINVAL; }
+extern "C" int htj2k_job_ht_blocks_per_wave(const htj2k_job *j) { return j ? j->ht_bpw : HTJ2K_ERR_EINVAL; }
 
 extern "C" int htj2k_job_idwt_hbm_bytes(htj2k_ctx *c, htj2k_job *j, double *bytes, int cap)
 {

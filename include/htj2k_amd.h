@@ -161,6 +161,10 @@ int  htj2k_job_idwt_launches(htj2k_ctx *ctx, htj2k_job *job, float *ms, double *
  * (exact: reversible 5/3 jobs whose every band has M_b <= 15, rgb24 output, all levels of even geometry; knob
  * "coef16", default on).  The reference holds them as int32 (comp->i_data, jpeg2000.c:499-511). */
 int  htj2k_job_coef16(const htj2k_job *job);
+/* codeblocks per wavefront in the MagSgn kernel of the last HT stage run: 1 (k_ht_decode: a lane per sample column), 2
+ * (k_ht_decode_pair, or k_ht_decode_multi with blocks of up to 64 columns), 4 (k_ht_decode_multi, blocks of up to 32
+ * columns); 0 before the first run.  Which kernel applies is decided per job: DESIGN.md section 3.1. */
+int  htj2k_job_ht_blocks_per_wave(const htj2k_job *job);
 /* 0: the last run held the LL bands between the IDWT levels as int32 (as the reference, jpeg2000dwt.c:539-581);
  * 1: as 16-bit samples (knob "ll16", jobs with 16-bit sub-bands only); 2: it did, a sample of an LL band did not fit
  * -- only crafted or corrupt coefficients do that -- and htj2k_job_wait / _download ran the transform again with
@@ -228,6 +232,9 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
+ *   "ht_multi"    1 (default): jobs with 32-bit sub-bands whose HT blocks all are cleanup-only, at most 64 columns wide,
+ *                 without ROI shift and of one transform decode 2 or 4 blocks per wavefront (k_ht_decode_multi); 0: one
+ *                 block per wavefront, a lane per sample column
  *   "coef16"      1 (default): jobs that qualify keep the sub-bands as 16-bit samples (htj2k_job_coef16)
  *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
  *   "ll16"        1 (default): such jobs also hold the LL bands between the IDWT levels as 16-bit samples, with a check

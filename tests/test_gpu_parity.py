@@ -428,6 +428,40 @@ def test_coef16_jobs_match_int32_jobs_and_the_oracle(dec, orc):
             assert np.array_equal(res[(1, 1)][0][0].reshape(info_o.height, info_o.width, 3), np.stack(img, -1)), key
 
 
+def test_multi_block_kernel_matches_the_column_kernel_and_the_oracle(dec, orc):
+    """jobs with 32-bit sub-bands whose HT blocks all are cleanup-only, at most 64 columns wide, without ROI shift and of
+    one transform decode 2 or 4 blocks per wavefront with a lane per quad (k_ht_decode_multi); the same streams with a
+    block per wavefront and a lane per sample column (k_ht_decode<true>, knob ht_multi 0) and the oracle give the same
+    frames.  The catalogue covers 5/3, 9/7 float and fixed point, 8 to 16 bits, odd widths and heights, tiles, offsets,
+    placeholder passes, 32- and 64-column blocks; streams that do not qualify must not take the kernel."""
+    seen = set()
+    dec.set_int("coef16", 0)                                   # so that the 8-bit streams qualify as well
+    try:
+        for name in sorted(streams.CASES):
+            data, kw = streams.get(name)
+            if kw.get("reduction_factor") or kw.get("bitexact"):
+                continue
+            info_o, planes_o, _ = orc.decode(data, **kw)
+            res = {}
+            for knob in (1, 0):
+                dec.set_int("ht_multi", knob)
+                job = dec.job().parse_batch([data, data]).upload().run().wait()
+                res[knob] = ([job.download_frame(f)[1] for f in range(2)], job.ht_blocks_per_wave(), job.block_errors())
+                job.free()
+            assert res[0][1] in (0, 1), name                     # 0: no HT block in the stream
+            seen.add(res[1][1])
+            assert res[1][2] == res[0][2] == orc.block_errors(), name
+            for f in range(2):
+                for a, b, c in zip(res[1][0][f], res[0][0][f], planes_o):
+                    assert np.array_equal(a, b) and np.array_equal(a, c), (name, res[1][1])
+            if any(t in name for t in ("3passes", "roi")):
+                assert res[1][1] in (0, 1), name
+    finally:
+        dec.set_int("ht_multi", 1)
+        dec.set_int("coef16", 1)
+    assert {1, 2, 4} <= seen, seen
+
+
 def test_coef16_is_not_used_where_it_does_not_apply(dec, orc):
     """odd geometry, 16-bit samples (M_b > 15), 9/7, refinement passes, Part-1 blocks, staged runs: int32 sub-bands as before"""
     for name in ("rgb_mct", "gray16", "rgb_97_ict", "rgb_3passes_cb32", "p1_rgb_mct", "gray_l5_cb64"):

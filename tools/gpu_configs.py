@@ -46,9 +46,9 @@ for name, mk in cfgs.items():
     info = job.frame_info(0)
     px = info.width * info.height * nb
     frac = lhb / (lms * 1e-3) / 8e12
-    print("%-28s %5.1f MB  ht %.3f  idwt %.3f  pack %.3f ms per %d frames -> %.1f Gpixel/s  blocks %d errs %d  IDWT %.0f GB/s of bytes that move = %.3f of 8 TB/s (algorithmic %.0f GB/s) coef16 %d ll16 %d" % (
+    print("%-28s %5.1f MB  ht %.3f  idwt %.3f  pack %.3f ms per %d frames -> %.1f Gpixel/s  blocks %d errs %d  IDWT %.0f GB/s of bytes that move = %.3f of 8 TB/s (algorithmic %.0f GB/s) coef16 %d ll16 %d bpw %d" % (
         name, len(data) / 1e6, acc[0], acc[1], acc[2], nb, px / acc.sum() / 1e6, job.num_blocks(), job.block_errors(),
-        lhb / (lms * 1e-3) / 1e9, frac, lalg / (lms * 1e-3) / 1e9, job.coef16(), job.ll16()), flush=True)
+        lhb / (lms * 1e-3) / 1e9, frac, lalg / (lms * 1e-3) / 1e9, job.coef16(), job.ll16(), job.ht_blocks_per_wave()), flush=True)
     print("      launches (us, MB, TB/s):", "  ".join("%.0f/%.0f/%.2f" % (v[0] / R * 1e3, v[1] / R / 1e6, v[1] / v[0] / 1e9) for v in per.values()), flush=True)
     out[name] = dict(frames_per_job=nb, ht_ms=round(float(acc[0]), 4), idwt_ms=round(float(acc[1]), 4), Gpixel_s=round(px / acc.sum() / 1e6, 1),
                      idwt_hbm_GBps=round(lhb / (lms * 1e-3) / 1e9, 1), idwt_frac_of_8TBps=round(frac, 4), idwt_algorithmic_GBps=round(lalg / (lms * 1e-3) / 1e9, 1),
