@@ -608,8 +608,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             const uint32_t tot = __builtin_amdgcn_sad_u8(N, 0u, 0u);         /* sum of the four bytes */
             const uint32_t incl = half_incl_scan_u32(tot);
             const uint32_t pos = ms_pos + incl - tot;
-            const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            ms_pos += hf ? end1 : end0;
+            ms_pos += (uint32_t)__builtin_amdgcn_ds_swizzle((int)incl, 31 << 5);   /* lane 31 of this half: one LDS-pipe op, no readlane + select */
             const uint32_t wi = min(pos >> 5, last_wi + 1);
             const uint32_t w0 = ms[wi], w1 = ms[wi + 1], w2 = ms[wi + 2];
             uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pos), hi = __builtin_amdgcn_alignbit(w2, w1, pos);
@@ -679,8 +678,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         const uint32_t tot = n0 + n1 + n2 + n3;
         const uint32_t incl = half_incl_scan_u32(tot);
         const uint32_t pos = ms_pos + incl - tot;
-        const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        ms_pos += hf ? end1 : end0;
+        ms_pos += (uint32_t)__builtin_amdgcn_ds_swizzle((int)incl, 31 << 5);
         /* every sample cuts its bits out of the two LDS words they start in (no register window: selecting the word
          * pair of a sample by a per-lane index makes the compiler put the window into scratch memory) */
         auto cut = [&](uint32_t p, uint32_t n) -> uint32_t {
