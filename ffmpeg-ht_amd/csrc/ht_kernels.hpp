@@ -1584,14 +1584,30 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     sp.init(spw, nsp);
     mr.init(mrw, nsp);
 
+    /* significance rows of quad row qy: the symbols of a row are read as dwords (two quads; rows are padded to an even
+     * number of quads and start on a dword), four at a time where the row pitch allows 16-byte loads -- a lane reads its
+     * own block's symbols, so every load instruction of the wave is 64 scattered requests and their number is what the
+     * kernel waits for */
+    const uint32_t qpitch = ht_qsym_pitch((uint32_t)w);
+    auto two_quads = [](uint32_t s2, int q, uint64_t &top, uint64_t &bot) {
+        const uint32_t r2 = (s2 | (s2 >> 1)) & 0x00550055u;           /* significance of sample n of quad q / q + 1 at bit 2 n / 16 + 2 n */
+        top |= (uint64_t)((r2 & 1u) | ((r2 >> 3) & 2u) | ((r2 >> 14) & 4u) | ((r2 >> 17) & 8u)) << (2 * q);            /* samples 0, 2 */
+        bot |= (uint64_t)(((r2 >> 2) & 1u) | ((r2 >> 5) & 2u) | ((r2 >> 16) & 4u) | ((r2 >> 19) & 8u)) << (2 * q);     /* samples 1, 3 */
+    };
     auto quad_rows = [&](int qy, uint64_t &top, uint64_t &bot) {
         top = 0; bot = 0;
         if (qy >= qh) return;
-        const ht_sym_t *row = qs + (size_t)qy * ht_qsym_pitch((uint32_t)w);
-        for (int q = 0; q < qw; q++) {
-            const uint32_t sy = row[q], rho = (sy | (sy >> 1)) & 0x55u;               /* significance of sample n at bit 2 n */
-            top |= (uint64_t)((rho & 1u) | ((rho >> 3) & 2u)) << (2 * q);            /* samples 0, 2 of the quad */
-            bot |= (uint64_t)(((rho >> 2) & 1u) | ((rho >> 5) & 2u)) << (2 * q);     /* samples 1, 3 */
+        const uint32_t *row = (const uint32_t *)(qs + (size_t)qy * qpitch);
+        if ((qpitch & 7) == 0) {
+            for (int q = 0; q < qw; q += 8) {
+                const uint4 s8 = *(const uint4 *)(row + (q >> 1));
+                two_quads(s8.x, q, top, bot);
+                two_quads(s8.y, q + 2, top, bot);
+                two_quads(s8.z, q + 4, top, bot);
+                two_quads(s8.w, q + 6, top, bot);
+            }
+        } else {
+            for (int q = 0; q < qw; q += 2) two_quads(row[q >> 1], q, top, bot);
         }
         top &= wmask; bot &= wmask;
         if (2 * qy + 1 >= h) bot = 0;
