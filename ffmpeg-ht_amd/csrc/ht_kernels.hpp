@@ -742,11 +742,15 @@ __device__ __forceinline__ uint32_t seg_last(uint32_t v)             /* the valu
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, LPB == 32 ? (31 << 5) : (0x10 | (15 << 5)));
 }
 
-template <int NB, int TRANSFORM>
+/* REFINE: some blocks of the job carry SigProp / MagRef passes; their decisions come from k_ht_refine as three 64-bit
+ * masks per sample row (newly significant, its sign, MagRef bit) and are applied to mu before the dequantisation, as
+ * in ht_magsgn_rows_narrow (jpeg2000htdec.c:1309-1315, :1066-1100, :1160-1185) */
+template <int NB, int TRANSFORM, bool REFINE>
 __global__ void __launch_bounds__(64)
 k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
                   uint32_t *__restrict__ coef, int *__restrict__ status, uint32_t ms_words,
-                  const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink)
+                  const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink,
+                  const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
 {
     constexpr int LPB = 64 / NB, PF = 16 / NB;               /* lanes per block; 256-byte pieces of a block's bytes requested up front */
     extern __shared__ __align__(16) uint8_t smem[];
@@ -852,6 +856,8 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
     const int qwp = (int)ht_qsym_pitch((uint32_t)w);
     const ht_sym_t *qp = qsym + qoff[bi] + q;
     uint32_t *prow = coef + b.plane_off + 2 * q;             /* this quad's two columns, row 2 * row */
+    const int z_blk = b.npasses - num_plhd;
+    const uint64_t *rb = (REFINE && ok && z_blk > 1) ? refbits + roff[bi] : nullptr;
     int rows = 0;
 #pragma unroll
     for (int hb = 0; hb < NB; hb++) rows = max(rows, __builtin_amdgcn_readlane(qh, hb * LPB));
@@ -901,8 +907,21 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         const int s0m = -(int)(R & 1), s1m = -(int)((R >> 8) & 1), s2m = -(int)((R >> 16) & 1), s3m = -(int)(R >> 24);
         E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
         E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
-        auto sample = [&](uint32_t v, int sm) -> uint32_t {              /* mu (:407-427) -> dequantisation */
-            const uint32_t mu = (((((v >> 1) + 1u) << pLSB) | halfbit) | (v << 31)) & (uint32_t)sm;
+        /* rows 2 * row and 2 * row + 1 of the refinement masks; this quad's columns are 2 q and 2 q + 1 */
+        uint64_t Rt = 0, Gt = 0, Qt = 0, Rb = 0, Gb = 0, Qb = 0;
+        if (REFINE && rb && row < qh) {
+            const uint64_t *r = rb + 6 * row;
+            Rt = r[0] >> (2 * q); Gt = r[1] >> (2 * q); Qt = r[2] >> (2 * q);
+            if (2 * row + 1 < h) { Rb = r[3] >> (2 * q); Gb = r[4] >> (2 * q); Qb = r[5] >> (2 * q); }
+        }
+        auto sample = [&](uint32_t v, int sm, uint32_t nsig, uint32_t sgn, uint32_t mrb) -> uint32_t {   /* mu (:407-427) -> dequantisation */
+            uint32_t mu = (((((v >> 1) + 1u) << pLSB) | halfbit) | (v << 31)) & (uint32_t)sm;
+            if (REFINE) {
+                const int qq = (pLSB - 1) & 31;
+                if (nsig & 1) mu |= (1u << qq) | (1u << ((qq - 1) & 31)) | (sgn << 31);
+                if (z_blk > 2 && sm) { mu &= (0xFFFFFFFEu | (mrb & 1)) << qq; mu |= 1u << ((qq - 1) & 31); }
+                return ht_dequant(mu, TRANSFORM, M_b, 0, fscale, i_step);
+            }
             if (TRANSFORM == J2K_DWT53) {
                 const int sg = (int)mu >> 31;
                 int r = (int)((mu & 0x7FFFFFFFu) >> dshift);
@@ -919,7 +938,10 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
                 return ht_dequant(mu, TRANSFORM, M_b, 0, fscale, i_step);
             }
         };
-        const uint32_t o0 = sample(v0, s0m), o1 = sample(v1, s1m), o2 = sample(v2, s2m), o3 = sample(v3, s3m);
+        const uint32_t o0 = sample(v0, s0m, (uint32_t)Rt, (uint32_t)Gt & 1, (uint32_t)Qt);
+        const uint32_t o1 = sample(v1, s1m, (uint32_t)Rb, (uint32_t)Gb & 1, (uint32_t)Qb);
+        const uint32_t o2 = sample(v2, s2m, (uint32_t)(Rt >> 1), (uint32_t)(Gt >> 1) & 1, (uint32_t)(Qt >> 1));
+        const uint32_t o3 = sample(v3, s3m, (uint32_t)(Rb >> 1), (uint32_t)(Gb >> 1) & 1, (uint32_t)(Qb >> 1));
         const bool two = 2 * row + 1 < h;
         /* a fixed number of stores per row behind the prefetch of the next row's symbols (vmcnt(N) stays exact): lanes
          * and rows with nothing to write aim at a scratch line */

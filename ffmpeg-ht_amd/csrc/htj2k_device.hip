@@ -1090,13 +1090,13 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         j->pair_ok = ok;
         /* k_ht_decode_multi: every block an HT block with the cleanup pass only, at most 64 columns, no ROI shift, one
          * transform for all of them; four blocks per wave when none is wider than 32 columns */
-        bool mok = j->nht == (int)j->blocks.size() && j->reflist.empty() && !j->blocks.empty();
+        /* (blocks with SigProp / MagRef passes of such jobs are all on k_ht_refine's list: same conditions) */
+        bool mok = j->nht == (int)j->blocks.size() && !j->blocks.empty();
         int maxw = 0;
         const int t0 = mok ? (j->blocks[0].flags & 3) : 0;
         for (size_t i = 0; mok && i < j->blocks.size(); i++) {
             const J2kBlock &b = j->blocks[i];
             mok = b.w <= 64 && b.roi_shift == 0 && (b.flags & 3) == t0;
-            if (mok && b.npasses) { const int rem = b.npasses % 3; mok = b.npasses - (rem ? b.npasses - rem : b.npasses - 3) == 1; }
             if (b.w > maxw) maxw = b.w;
         }
         j->multi_nb = mok ? (maxw <= 32 ? 4 : 2) : 0;
@@ -1395,19 +1395,22 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 else if (!j->coef_is16 && j->multi_nb && c->ht_multi) {
                     const int nb = j->multi_nb;
                     const size_t lds = (size_t)nb * (j->lds_ext.ms_words + 4) * 4;
-#define HT_MULTI(NB_, T_) do { \
-                        if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode_multi<NB_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                        hipLaunchKernelGGL((k_ht_decode_multi<NB_, T_>), dim3((nblocks + NB_ - 1) / NB_), dim3(64), lds, j->stream, \
+#define HT_MULTI_R(NB_, T_, R_) do { \
+                        if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode_multi<NB_, T_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        hipLaunchKernelGGL((k_ht_decode_multi<NB_, T_, R_>), dim3((nblocks + NB_ - 1) / NB_), dim3(64), lds, j->stream, \
                                            (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p, \
                                            (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words, \
                                            (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, \
-                                           (uint32_t *)j->d_coef.p + j->nsamples + 32); } while (0)
+                                           (uint32_t *)j->d_coef.p + j->nsamples + 32, \
+                                           (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p); } while (0)
+#define HT_MULTI(NB_, T_) do { if (j->reflist.empty()) HT_MULTI_R(NB_, T_, false); else HT_MULTI_R(NB_, T_, true); } while (0)
                     if (nb == 4) {
                         if (j->multi_t == J2K_DWT53) HT_MULTI(4, J2K_DWT53); else if (j->multi_t == J2K_DWT97) HT_MULTI(4, J2K_DWT97); else HT_MULTI(4, J2K_DWT97_INT);
                     } else {
                         if (j->multi_t == J2K_DWT53) HT_MULTI(2, J2K_DWT53); else if (j->multi_t == J2K_DWT97) HT_MULTI(2, J2K_DWT97); else HT_MULTI(2, J2K_DWT97_INT);
                     }
 #undef HT_MULTI
+#undef HT_MULTI_R
                 } else
                 hipLaunchKernelGGL(k_ht_decode<true>, dim3(nblocks), dim3(64), j->lds_ext.total, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
