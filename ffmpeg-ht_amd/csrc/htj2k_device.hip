@@ -131,6 +131,9 @@ struct htj2k_ctx {
     int ht_mode = 1;                   /* 0 = one kernel (serial stage on lane 0), 1 = k_ht_vlc (lane per block) + k_ht_decode<true> */
     int max_dyn_lds = 64 * 1024;
     int parse_threads = 0;             /* host threads that parse the frames of a batch; 0 = min(cores, 16) */
+    int packet_threads = 1;            /* > 1: a frame parsed on its own (htj2k_decode, batches of one) has the packets of tiles with a
+                                        * PLT list read by this many threads (j2k_parser_set_packet_threads); off by default:
+                                        * at 0.4 ms per 4K frame waking the threads costs what they save */
     int device_gather = 1;             /* 1: the packets are uploaded as they are and k_gather puts the byte pool together on the
                                         * device (the parser does not touch code-block bytes); 0: the parser gathers on the host */
     std::mutex log_mutex;
@@ -335,6 +338,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "device_gather")) { c->device_gather = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "packet_threads")) { c->packet_threads = value < 1 ? 1 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
@@ -464,6 +468,7 @@ extern "C" int htj2k_job_parse_batch_ex(htj2k_ctx *c, const uint8_t *const *pkts
         F.h_bytes.device = c->device;
         F.h_pkt.device = c->device;
         j2k_parser_set_gather(F.parser, !j->dev_gather);
+        j2k_parser_set_packet_threads(F.parser, n == 1 ? c->packet_threads : 1);   /* batches: one frame per thread instead */
         j2k_parser_set_bytes_alloc(F.parser, [](void *opaque, size_t nb) -> void * { return ((HostBuf *)opaque)->ensure(nb); },
                                    &F.h_bytes);
         F.plan = nullptr;

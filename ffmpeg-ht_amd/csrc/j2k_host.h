@@ -127,6 +127,11 @@ typedef struct TileHdr {
     uint8_t    own_params;                 /* TILE_* */
     uint8_t   *ppt; int ppt_size; Cur ppt_cur;
     int32_t    x0, x1, y0, y1;             /* on the reference grid */
+    /* packet lengths of the tile's PLT segments, in the order they appear (the reference reads and drops them,
+     * jpeg2000dec.c:901-956; here they let several threads read the packets of a tile, j2k_tier2.c) */
+    uint32_t  *plt; uint32_t nplt, plt_cap;
+    uint32_t   plt_acc;                    /* the length being assembled from 7-bit pieces */
+    uint8_t    plt_open, plt_bad;          /* a length is unfinished at the end of a segment / the list is unusable */
 } TileHdr;
 
 /* ------------------------------------------------------------------ geometry tables */
@@ -212,6 +217,11 @@ struct J2kParser {
     j2k_bytes_alloc_fn bytes_alloc; void *bytes_alloc_opaque;
     htj2k_opts opts;
     int gather_on_host;                        /* 1 (default): J2kPlan.bytes is filled by the parser */
+    int packet_threads;                        /* > 1: tiles with a complete PLT list and one layer have their packets read by
+                                                * this many threads (t2_read_tile_packets) */
+    struct PktPool *pool;                      /* ... which live here between frames */
+    int seq_only;                              /* set while a frame is parsed again after the parallel reader gave up */
+    uint32_t parallel_tiles, parallel_retries; /* statistics: tiles read in parallel, frames parsed again */
 
     /* ---- codestream-level state of the frame being parsed ---- */
     const uint8_t *pkt; int pkt_size;
@@ -266,7 +276,9 @@ static inline int64_t pixel_budget(const J2kParser *ps) { return ps->opts.max_pi
 
 /* j2k_tier2.c */
 int  t2_build_geometry(J2kParser *ps);         /* fills ps->geo from the resolved tile headers (or finds it cached) */
-int  t2_read_tile_packets(J2kParser *ps, int tileno);
+int  t2_read_tile_packets(J2kParser *ps, int tileno);   /* < 0: error; T2_AGAIN_SEQUENTIAL: parse the frame again with seq_only */
+#define T2_AGAIN_SEQUENTIAL 0x7fff0001
+void t2_pool_free(J2kParser *ps);
 
 /* small arithmetic shared by all */
 static inline int32_t cdiv_pow2(int32_t a, int s) { return (int32_t)-((-(int64_t)a) >> s); }

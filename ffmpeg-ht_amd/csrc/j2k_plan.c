@@ -25,6 +25,7 @@ void j2k_parser_free(J2kParser *ps)
 {
     if (!ps)
         return;
+    t2_pool_free(ps);
     pool_destroy(&ps->frame);
     pool_destroy(&ps->geo.pool);
     free(ps->geo.sig); free(ps->geo.pb); free(ps->geo.rows); free(ps->geo.row_blk); free(ps->geo.row_aux); free(ps->geo.row_tc);
@@ -58,6 +59,12 @@ static void begin_frame(J2kParser *ps)
 }
 
 void j2k_parser_set_gather(J2kParser *ps, int on_host) { ps->gather_on_host = on_host != 0; }
+void j2k_parser_set_packet_threads(J2kParser *ps, int n) { ps->packet_threads = n < 1 ? 1 : (n > 16 ? 16 : n); }
+void j2k_parser_parallel_stats(const J2kParser *ps, uint32_t *tiles, uint32_t *retries)
+{
+    if (tiles) *tiles = ps->parallel_tiles;
+    if (retries) *retries = ps->parallel_retries;
+}
 
 /* the reference implementation of the gather: k_gather (htj2k_device.hip) does the same on the device.  The pieces
  * are in pool order, so one pass writes every byte of the pool once: pieces, and zeros in the gaps between them. */
@@ -291,7 +298,21 @@ static int assemble_plan(J2kParser *ps)
     return 0;
 }
 
+static int parse_frame(J2kParser *ps, const uint8_t *pkt, int size, const htj2k_opts *opts, int headers_only, const J2kPlan **plan);
+
 int j2k_parse(J2kParser *ps, const uint8_t *pkt, int size, const htj2k_opts *opts, int headers_only, const J2kPlan **plan)
+{
+    int r = parse_frame(ps, pkt, size, opts, headers_only, plan);
+    if (r == T2_AGAIN_SEQUENTIAL) {                        /* the parallel packet reader gave up: the frame again, without it */
+        ps->parallel_retries++;
+        ps->seq_only = 1;
+        r = parse_frame(ps, pkt, size, opts, headers_only, plan);
+        ps->seq_only = 0;
+    }
+    return r;
+}
+
+static int parse_frame(J2kParser *ps, const uint8_t *pkt, int size, const htj2k_opts *opts, int headers_only, const J2kPlan **plan)
 {
     int r, tileno;
 
@@ -337,7 +358,7 @@ int j2k_parse(J2kParser *ps, const uint8_t *pkt, int size, const htj2k_opts *opt
     if (!ps->blk || !ps->nodes || !ps->layers_done)
         return HTJ2K_ERR_ENOMEM;
     for (tileno = 0; tileno < ps->geo.ntiles; tileno++)
-        if ((r = t2_read_tile_packets(ps, tileno)) < 0)
+        if ((r = t2_read_tile_packets(ps, tileno)) != 0)
             return r;
     ps->plan.bytes_consumed = cur_pos(&ps->g);
     if ((r = assemble_plan(ps)) < 0)

@@ -150,6 +150,13 @@ void       j2k_parser_set_bytes_alloc(J2kParser *p, j2k_bytes_alloc_fn fn, void 
 /* on (default): j2k_parse fills J2kPlan.bytes; off: only the gather table is made and no code-block byte is read
  * except the two that hold Scup */
 void       j2k_parser_set_gather(J2kParser *p, int on_host);
+/* n > 1: the packets of a tile are read by n threads where the stream allows it -- a PLT packet-length list that covers
+ * the tile, no PPM / PPT, one quality layer; everything else, and every frame in which anything at all disagrees with the
+ * list, is read by the calling thread as before (same plan, same messages).  For callers that decode one frame at a time;
+ * batches are better served by one frame per thread (htj2k_job_parse_batch). */
+void       j2k_parser_set_packet_threads(J2kParser *p, int n);
+/* tiles the parallel reader has read / frames it gave up on, since the parser was made */
+void       j2k_parser_parallel_stats(const J2kParser *p, uint32_t *tiles, uint32_t *retries);
 /* the byte pool of a plan, nbytes + 64 bytes, written to dst (what the parser does itself when gathering is on) */
 void       j2k_plan_gather(const J2kPlan *plan, uint8_t *dst);
 

@@ -795,14 +795,41 @@ static int seg_tlm(J2kParser *ps, Cur *c, int lseg)
  * end a length */
 static int seg_plt(J2kParser *ps, Cur *c, int lseg)
 {
+    TileHdr *t = ps->cur_tile >= 0 ? &ps->tile[ps->cur_tile] : NULL;
     uint32_t last = 0;
     int i;
-    (void)ps;
     if (lseg < 4)
         return HTJ2K_ERR_INVALIDDATA;
-    cur_u8(c);
-    for (i = 0; i < lseg - 3; i++)
+    cur_u8(c);                                             /* Zplt: the segments are taken in the order they come */
+    if (t && t->plt_open)
+        t->plt_bad = 1;                                    /* a length does not continue across segments */
+    for (i = 0; i < lseg - 3; i++) {
         last = cur_u8(c);
+        if (!t || t->plt_bad)
+            continue;
+        if (t->plt_acc >> 25) {                            /* more than 32 bits */
+            t->plt_bad = 1;
+            continue;
+        }
+        t->plt_acc = (t->plt_acc << 7) | (last & 0x7F);
+        t->plt_open = (uint8_t)(last >> 7);
+        if (!t->plt_open) {
+            if (t->nplt == t->plt_cap) {
+                const uint32_t nc = t->plt_cap ? 2 * t->plt_cap : 1024;
+                uint32_t *nb = (uint32_t *)pool_get(&ps->frame, (size_t)nc * sizeof *nb, 0);
+                if (!nb) {
+                    t->plt_bad = 1;
+                    continue;
+                }
+                if (t->nplt)
+                    memcpy(nb, t->plt, (size_t)t->nplt * sizeof *nb);
+                t->plt = nb;
+                t->plt_cap = nc;
+            }
+            t->plt[t->nplt++] = t->plt_acc;
+            t->plt_acc = 0;
+        }
+    }
     return (last & 0x80) ? HTJ2K_ERR_INVALIDDATA : 0;
 }
 

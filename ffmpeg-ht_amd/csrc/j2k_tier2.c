@@ -652,7 +652,16 @@ typedef struct PacketCtx {
     /* lengths signalled by the header being read, in body order */
     uint32_t *lens; uint32_t nlens, lens_cap;
     Contribution *con; uint32_t ncon, con_cap;
+    /* a worker of the parallel reader (read_tile_parallel): the packet sits at *at, its end goes to end_p, nothing is said
+     * (anything worth a message makes the tile `anomalous` and the frame is parsed again the sequential way, which
+     * then says it), and chained pieces come out of the worker's own slice of the table */
+    const Cur *at;
+    const uint8_t *end_p;
+    int quiet, anomaly;
+    uint32_t arena_next, arena_limit;
 } PacketCtx;
+
+#define PKT_LOG(pc, level, ...) do { if ((pc)->quiet) (pc)->anomaly = 1; else cs_log((pc)->ps, level, __VA_ARGS__); } while (0)
 
 static int note_length(PacketCtx *pc, uint32_t len)
 {
@@ -669,9 +678,11 @@ static int note_length(PacketCtx *pc, uint32_t len)
 }
 
 /* one more piece of a block's byte string; adjacent unterminated pieces become one */
-static int add_piece(J2kParser *ps, BlkState *s, uint32_t src, uint32_t len, int term)
+static int add_piece(PacketCtx *pc, BlkState *s, uint32_t src, uint32_t len, int term)
 {
+    J2kParser *ps = pc->ps;
     SegNode *last = s->last ? &ps->segs[s->last - 1] : NULL;
+    uint32_t idx;
     if (!(s->flags & BS_HAS_BYTES)) {
         s->flags |= BS_HAS_BYTES;
         s->first_src = src; s->first_len = len; s->first_term = (uint8_t)term;
@@ -682,20 +693,28 @@ static int add_piece(J2kParser *ps, BlkState *s, uint32_t src, uint32_t len, int
         else      { s->first_len += len; s->first_term = (uint8_t)term; }
         return 0;
     }
-    if (ps->nsegs == ps->segs_cap) {
-        const uint32_t nc = ps->segs_cap ? ps->segs_cap * 2 : 4096;
-        SegNode *ns = (SegNode *)realloc(ps->segs, (size_t)nc * sizeof *ns);
-        if (!ns)
-            return HTJ2K_ERR_ENOMEM;
-        ps->segs = ns;
-        ps->segs_cap = nc;
-        last = s->last ? &ps->segs[s->last - 1] : NULL;
+    if (pc->arena_limit) {                                 /* (the table does not move while the workers run) */
+        if (pc->arena_next == pc->arena_limit) {
+            pc->anomaly = 1;
+            return HTJ2K_ERR_BUG;
+        }
+        idx = pc->arena_next++;
+    } else {
+        if (ps->nsegs == ps->segs_cap) {
+            const uint32_t nc = ps->segs_cap ? ps->segs_cap * 2 : 4096;
+            SegNode *ns = (SegNode *)realloc(ps->segs, (size_t)nc * sizeof *ns);
+            if (!ns)
+                return HTJ2K_ERR_ENOMEM;
+            ps->segs = ns;
+            ps->segs_cap = nc;
+            last = s->last ? &ps->segs[s->last - 1] : NULL;
+        }
+        idx = ps->nsegs++;
     }
-    ps->segs[ps->nsegs].src = src; ps->segs[ps->nsegs].len = len;
-    ps->segs[ps->nsegs].term = (uint32_t)term; ps->segs[ps->nsegs].next = 0;
-    ps->nsegs++;
-    if (last) last->next = ps->nsegs; else s->more = ps->nsegs;
-    s->last = ps->nsegs;
+    ps->segs[idx].src = src; ps->segs[idx].len = len;
+    ps->segs[idx].term = (uint32_t)term; ps->segs[idx].next = 0;
+    if (last) last->next = idx + 1; else s->more = idx + 1;
+    s->last = idx + 1;
     return 0;
 }
 
@@ -711,7 +730,7 @@ static Cur body_stream(PacketCtx *pc, const CompCoding *k)
         if (cur_peek32(&c) == 0xFF910004u)
             cur_skip(&c, 6);
         else
-            cs_log(pc->ps, LOGL_ERROR, "no SOP marker in front of a packet (%08x)\n", (unsigned)cur_peek32(&c));
+            PKT_LOG(pc, LOGL_ERROR, "no SOP marker in front of a packet (%08x)\n", (unsigned)cur_peek32(&c));
     }
     return c;
 }
@@ -722,7 +741,7 @@ static Cur header_stream(PacketCtx *pc, const CompCoding *k)
     if (ps->has_ppm) {
         Cur c = pc->tile->part[pc->part].hdr;
         if (!cur_left(&c)) {
-            cs_log(ps, LOGL_WARNING, "the packed packet headers of tile-part %d are used up\n", pc->part);
+            PKT_LOG(pc, LOGL_WARNING, "the packed packet headers of tile-part %d are used up\n", pc->part);
             if (pc->part < CS_MAX_TPARTS - 1)
                 c = pc->tile->part[++pc->part].body;       /* (the body, not the headers: reference behaviour) */
         }
@@ -741,7 +760,7 @@ static Cur header_done(PacketCtx *pc, const CompCoding *k, Cur c)
         if (cur_peek16(&c) == 0xFF92)
             cur_skip(&c, 2);
         else
-            cs_log(ps, LOGL_ERROR, "no EPH marker behind a packet header (%08x)\n", (unsigned)cur_peek32(&c));
+            PKT_LOG(pc, LOGL_ERROR, "no EPH marker behind a packet header (%08x)\n", (unsigned)cur_peek32(&c));
     }
     if (ps->has_ppm) {
         pc->tile->part[pc->part].hdr = c;
@@ -758,7 +777,6 @@ static Cur header_done(PacketCtx *pc, const CompCoding *k, Cur c)
  *      lblock + floor(log2(passes in the segment)) bits.  Returns < 0 on failure. ---- */
 static int read_segment_lengths(PacketCtx *pc, BitWin *w, BlkState *s, int fresh)
 {
-    J2kParser *ps = pc->ps;
     int seg, nbits, follow = 0, bypass = 0, left, r;
     uint32_t bytes;
 
@@ -780,7 +798,7 @@ static int read_segment_lengths(PacketCtx *pc, BitWin *w, BlkState *s, int fresh
                     s->flags &= (uint8_t)~BS_PLACEHOLD;
                     s->style &= (uint8_t)~CBS_HT;
                 } else {
-                    cs_log(ps, LOGL_WARNING, "HT block: bytes signalled for placeholder passes\n");
+                    PKT_LOG(pc, LOGL_WARNING, "HT block: bytes signalled for placeholder passes\n");
                 }
             }
         } else {
@@ -793,7 +811,7 @@ static int read_segment_lengths(PacketCtx *pc, BitWin *w, BlkState *s, int fresh
                 s->flags &= (uint8_t)~BS_PLACEHOLD;
                 if (looks_ht) {
                     if (bytes < 2)
-                        cs_log(ps, LOGL_WARNING, "HT block: cleanup segment of %u byte\n", (unsigned)bytes);
+                        PKT_LOG(pc, LOGL_WARNING, "HT block: cleanup segment of %u byte\n", (unsigned)bytes);
                     follow = 2;
                     s->lcup = bytes;
                 } else {
@@ -817,7 +835,7 @@ static int read_segment_lengths(PacketCtx *pc, BitWin *w, BlkState *s, int fresh
                             s->style &= (uint8_t)~CBS_HT;
                             s->flags &= (uint8_t)~BS_PLACEHOLD;
                         } else {
-                            cs_log(ps, LOGL_WARNING, "HT block: bytes signalled for placeholder passes\n");
+                            PKT_LOG(pc, LOGL_WARNING, "HT block: bytes signalled for placeholder passes\n");
                         }
                     }
                 }
@@ -884,7 +902,7 @@ static int read_segment_lengths(PacketCtx *pc, BitWin *w, BlkState *s, int fresh
                 nbits = s->lblock + ilog2u((uint32_t)seg);
             } else {
                 if (!(s->style & CBS_TERMALL))
-                    cs_log(ps, LOGL_WARNING, "packet header: more passes than its one segment can hold\n");
+                    PKT_LOG(pc, LOGL_WARNING, "packet header: more passes than its one segment can hold\n");
                 seg = 1;
                 nbits = s->lblock;
             }
@@ -915,11 +933,20 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
     int b, ret;
     uint32_t i;
 
-    if (layer < *done)
-        return 0;                                          /* a progression change revisits the packet */
-    *done = (uint8_t)(layer + 1);
-
-    c = header_stream(pc, k);
+    if (pc->at) {                                          /* parallel reader: the list was made with the revisits left out */
+        c = *pc->at;
+        if (k->scod & SCOD_SOP) {
+            if (cur_peek32(&c) == 0xFF910004u)
+                cur_skip(&c, 6);
+            else
+                pc->anomaly = 1;
+        }
+    } else {
+        if (layer < *done)
+            return 0;                                      /* a progression change revisits the packet */
+        *done = (uint8_t)(layer + 1);
+        c = header_stream(pc, k);
+    }
     bw_open(&w, &c);
     pc->nlens = pc->ncon = 0;
     if (bw_take(&w, 1)) {                                  /* the packet is not empty */
@@ -953,7 +980,7 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
                         const int zbp = tagtree_read(&w, zbp_tree, pb->ncw, pb->nch, bx, by, 100);
                         const int nzb = expn[b] + q->guard - 1 - (zbp - pc->tile->roi[0]);
                         if (nzb < 0 || nzb > 30) {
-                            cs_log(ps, LOGL_ERROR, "code-block with %d magnitude bit-planes\n", nzb);
+                            PKT_LOG(pc, LOGL_ERROR, "code-block with %d magnitude bit-planes\n", nzb);
                             return HTJ2K_ERR_INVALIDDATA;
                         }
                         s->flags |= BS_INCLUDED;
@@ -969,13 +996,13 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
 
                 fresh = read_pass_count(&w);
                 if (s->npasses + fresh >= CS_MAX_PASSES) {
-                    cs_log(ps, LOGL_ERROR, "code-block with %d coding passes\n", s->npasses + fresh);
+                    PKT_LOG(pc, LOGL_ERROR, "code-block with %d coding passes\n", s->npasses + fresh);
                     return HTJ2K_ERR_PATCHWELCOME;
                 }
                 for (grow_by = 0; bw_take(&w, 1); grow_by++)   /* Lblock increment: a comma code */
                     ;
                 if (s->lblock + grow_by + ilog2u((uint32_t)fresh) > 16) {
-                    cs_log(ps, LOGL_ERROR, "code-block segment length field wider than 16 bits\n");
+                    PKT_LOG(pc, LOGL_ERROR, "code-block segment length field wider than 16 bits\n");
                     return HTJ2K_ERR_PATCHWELCOME;
                 }
                 s->lblock = (uint8_t)(s->lblock + grow_by);
@@ -1002,6 +1029,8 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
         }
     }
     c.p = bw_close(&w);
+    if (pc->at && w.fed_past_end)
+        pc->anomaly = 1;                                   /* the header ran past the end the list gives the packet */
     c = header_done(pc, k, c);
 
     /* the body: the signalled bytes of every contributing block, in header order */
@@ -1013,7 +1042,7 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
             const uint32_t len = pc->lens[cn->first + j];
             /* a block's bytes are counted in 16 bits (Jpeg2000Cblk.length, jpeg2000.h:188) */
             if ((uint32_t)cur_left(&c) < len || s->length + len > 65535u || (todo_term && s->length + len + 2 > 65535u)) {
-                cs_log(ps, LOGL_ERROR, "code-block bytes: %u so far, %u more signalled, %d left in the tile-part\n",
+                PKT_LOG(pc, LOGL_ERROR, "code-block bytes: %u so far, %u more signalled, %d left in the tile-part\n",
                        (unsigned)s->length, (unsigned)len, cur_left(&c));
                 return HTJ2K_ERR_INVALIDDATA;
             }
@@ -1021,7 +1050,7 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
                 /* the plan will want Scup, the last two bytes of an HT block's cleanup segment: have them on their way */
                 if (!j && len > 1 && (s->style & CBS_HT) && !(s->flags & BS_HAS_BYTES))
                     __builtin_prefetch(c.p + len - 1);
-                if ((ret = add_piece(ps, s, (uint32_t)(c.p - ps->pkt), len, todo_term != 0)) < 0)
+                if ((ret = add_piece(pc, s, (uint32_t)(c.p - ps->pkt), len, todo_term != 0)) < 0)
                     return ret;
             }
             c.p += len;
@@ -1032,6 +1061,10 @@ static int read_packet(PacketCtx *pc, int comp, int r, int prec, int layer)
                 s->length += 2;
             }
         }
+    }
+    if (pc->at) {
+        pc->end_p = c.p;
+        return 0;
     }
     pc->tile->part[pc->part].body = c;
     ps->g = c;
@@ -1058,7 +1091,38 @@ typedef struct PacketWalk {
     int layer, res, comp, prec, x, y;
     int step_x, step_y;                                    /* position progressions: grid pitch on the reference grid */
     int hit;                                               /* RPCL: some position of this resolution started a precinct */
+    /* list mode (parallel reader): the packets are noted in order instead of being read */
+    struct PktRef *list; uint32_t nlist, list_cap;
+    int list_mode;
 } PacketWalk;
+
+typedef struct PktRef { uint32_t prec; uint16_t comp; uint8_t res, layer; } PktRef;
+
+static int visit_packet(PacketWalk *pw, int comp, int r, int prec, int layer)
+{
+    J2kParser *ps = pw->pc->ps;
+    const ResGeom *rg;
+    uint8_t *done;
+    if (!pw->list_mode)
+        return read_packet(pw->pc, comp, r, prec, layer);
+    rg = &ps->geo.tc[pw->pc->tileno * ps->ncomp + comp].res[r];
+    done = &ps->layers_done[rg->lay0 + (uint32_t)prec];
+    if (layer < *done)
+        return 0;                                          /* as read_packet: a progression change revisits the packet */
+    *done = (uint8_t)(layer + 1);
+    if (pw->nlist == pw->list_cap) {
+        const uint32_t nc = pw->list_cap ? 2 * pw->list_cap : 4096;
+        PktRef *nl = (PktRef *)realloc(pw->list, (size_t)nc * sizeof *nl);
+        if (!nl)
+            return HTJ2K_ERR_ENOMEM;
+        pw->list = nl;
+        pw->list_cap = nc;
+    }
+    pw->list[pw->nlist].prec = (uint32_t)prec; pw->list[pw->nlist].comp = (uint16_t)comp;
+    pw->list[pw->nlist].res = (uint8_t)r; pw->list[pw->nlist].layer = (uint8_t)layer;
+    pw->nlist++;
+    return 0;
+}
 
 /* position progressions: the precinct of (comp, res) that starts at reference-grid position (x, y), or -1
  * (jpeg2000dec.c:1701-1745, 1784-1821 for RPCL / PCRL; :1642-1690 for CPRL, whose tests differ) */
@@ -1092,7 +1156,7 @@ static int precinct_at(PacketWalk *pw)
     px -= (uint32_t)(cdiv_pow2(tc->ox0, down) >> rg->ppx);
     py -= (uint32_t)(cdiv_pow2(tc->oy0, down) >> rg->ppy);
     if (px >= (uint32_t)rg->npx || py >= (uint32_t)rg->npy) {
-        cs_log(ps, LOGL_WARNING, "precinct (%u, %u) outside the %d x %d grid of its resolution\n", (unsigned)px, (unsigned)py, rg->npx, rg->npy);
+        PKT_LOG(pw->pc, LOGL_WARNING, "precinct (%u, %u) outside the %d x %d grid of its resolution\n", (unsigned)px, (unsigned)py, rg->npx, rg->npy);
         return -1;
     }
     return (int)(px + (uint32_t)rg->npx * py);
@@ -1133,7 +1197,7 @@ static int walk(PacketWalk *pw, int depth)
         int prec = pw->prec;
         if (positional && (prec = precinct_at(pw)) < 0)
             return 0;
-        return read_packet(pc, pw->comp, pw->res, prec, pw->layer);
+        return visit_packet(pw, pw->comp, pw->res, prec, pw->layer);
     }
     case AX_LAYER:
         if (positional) {
@@ -1142,7 +1206,7 @@ static int walk(PacketWalk *pw, int depth)
             if (prec < 0)
                 return 0;
             for (pw->layer = 0; pw->layer < v->lye; pw->layer++)
-                if ((ret = read_packet(pc, pw->comp, pw->res, prec, pw->layer)) < 0)
+                if ((ret = visit_packet(pw, pw->comp, pw->res, prec, pw->layer)) < 0)
                     return ret;
             return 0;
         }
@@ -1185,7 +1249,7 @@ static int walk(PacketWalk *pw, int depth)
                     continue;
                 position_steps(pw, pw->comp, pw->comp + 1, v->rs, v->re, 32, &pw->step_x, &pw->step_y);
                 if (pw->step_x >= 31 || pw->step_y >= 31) {
-                    cs_log(ps, LOGL_ERROR, "CPRL: precinct pitch beyond 2^30\n");
+                    PKT_LOG(pw->pc, LOGL_ERROR, "CPRL: precinct pitch beyond 2^30\n");
                     return HTJ2K_ERR_PATCHWELCOME;
                 }
                 pw->step_x = 1 << pw->step_x;
@@ -1209,7 +1273,7 @@ static int walk(PacketWalk *pw, int depth)
         if (pw->order == 3) {
             position_steps(pw, v->cs, v->ce, v->rs, v->re, 32, &pw->step_x, &pw->step_y);
             if (pw->step_x >= 31 || pw->step_y >= 31) {
-                cs_log(ps, LOGL_ERROR, "PCRL: precinct pitch beyond 2^30\n");
+                PKT_LOG(pw->pc, LOGL_ERROR, "PCRL: precinct pitch beyond 2^30\n");
                 return HTJ2K_ERR_PATCHWELCOME;
             }
             pw->step_x = 1 << pw->step_x;
@@ -1229,35 +1293,269 @@ static int walk(PacketWalk *pw, int depth)
     return HTJ2K_ERR_BUG;
 }
 
-/* all packets of a tile (jpeg2000_decode_packets, jpeg2000dec.c:1835-1869) */
-int t2_read_tile_packets(J2kParser *ps, int tileno)
+/* ================================================================== the packets of a tile on several threads
+ * A PLT marker segment lists the length of every packet of its tile-part (T.800 A.7.3).  The reference reads and
+ * drops the list (jpeg2000dec.c:901-956); a packet header can only be found by reading the one before it, so its packet
+ * reader is one chain per tile.  With the list, where every packet starts is known beforehand, and with one quality
+ * layer no packet needs what another left behind (inclusion and zero-bit-plane trees, Lblock and pass counts are per
+ * code-block, a code-block belongs to one precinct, a precinct has one packet per layer): the packets of the tile are
+ * dealt out to threads in contiguous runs of about equal bytes.
+ * The sequential reader stays the definition of what a stream means.  The parallel one reads a tile only if the list is
+ * complete and plausible, the packets are where it says, every packet ends where the list says it ends, and nothing
+ * came up that the sequential reader would have had something to say about; otherwise the frame is parsed again
+ * from the start without it (T2_AGAIN_SEQUENTIAL) -- same plan, same messages, same errors as ever. */
+#include <pthread.h>
+
+#define PAR_MAX_THREADS 16
+
+struct PktPool;
+typedef struct PoolSlot { struct PktPool *pool; int tid; } PoolSlot;
+
+typedef struct PktPool {
+    pthread_t th[PAR_MAX_THREADS - 1];
+    PoolSlot slot[PAR_MAX_THREADS - 1];
+    int nth;                                               /* helpers besides the calling thread */
+    pthread_mutex_t m;
+    pthread_cond_t go, done;
+    uint64_t gen;
+    int pending, quit, active;                             /* helpers 1 .. active - 1 take part in the current run */
+    void (*fn)(void *, int);
+    void *arg;
+    /* kept between frames */
+    PktRef *list; uint32_t list_cap;
+    Cur *starts; uint32_t starts_cap;
+    uint32_t *lens[PAR_MAX_THREADS]; uint32_t lens_cap[PAR_MAX_THREADS];
+    Contribution *con[PAR_MAX_THREADS]; uint32_t con_cap[PAR_MAX_THREADS];
+} PktPool;
+
+static void *pool_helper(void *v)
 {
-    TileHdr *t = &ps->tile[tileno];
-    PacketCtx pc;
-    PacketWalk pw;
+    PoolSlot *me = (PoolSlot *)v;
+    PktPool *p = me->pool;
+    uint64_t seen = 0;
+    for (;;) {
+        void (*fn)(void *, int);
+        void *arg;
+        pthread_mutex_lock(&p->m);
+        while (p->gen == seen && !p->quit)
+            pthread_cond_wait(&p->go, &p->m);
+        if (p->quit) {
+            pthread_mutex_unlock(&p->m);
+            return NULL;
+        }
+        seen = p->gen;
+        fn = p->fn; arg = p->arg;
+        if (me->tid >= p->active) {                        /* not needed this time */
+            pthread_mutex_unlock(&p->m);
+            continue;
+        }
+        pthread_mutex_unlock(&p->m);
+        fn(arg, me->tid);
+        pthread_mutex_lock(&p->m);
+        if (--p->pending == 0)
+            pthread_cond_signal(&p->done);
+        pthread_mutex_unlock(&p->m);
+    }
+}
+
+static PktPool *pool_get_threads(J2kParser *ps, int want)     /* want: threads including the caller */
+{
+    PktPool *p = ps->pool;
+    if (!p) {
+        p = (PktPool *)calloc(1, sizeof *p);
+        if (!p)
+            return NULL;
+        pthread_mutex_init(&p->m, NULL);
+        pthread_cond_init(&p->go, NULL);
+        pthread_cond_init(&p->done, NULL);
+        ps->pool = p;
+    }
+    while (p->nth < want - 1 && p->nth < PAR_MAX_THREADS - 1) {
+        p->slot[p->nth].pool = p;
+        p->slot[p->nth].tid = p->nth + 1;
+        if (pthread_create(&p->th[p->nth], NULL, pool_helper, &p->slot[p->nth]))
+            break;
+        p->nth++;
+    }
+    return p;
+}
+
+static void pool_run(PktPool *p, void (*fn)(void *, int), void *arg, int nworkers)
+{
+    pthread_mutex_lock(&p->m);
+    p->fn = fn; p->arg = arg;
+    p->active = nworkers;
+    p->pending = nworkers - 1;
+    p->gen++;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->m);
+    fn(arg, 0);
+    pthread_mutex_lock(&p->m);
+    while (p->pending)
+        pthread_cond_wait(&p->done, &p->m);
+    pthread_mutex_unlock(&p->m);
+}
+
+void t2_pool_free(J2kParser *ps)
+{
+    PktPool *p = ps->pool;
+    int i;
+    if (!p)
+        return;
+    pthread_mutex_lock(&p->m);
+    p->quit = 1;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->m);
+    for (i = 0; i < p->nth; i++)
+        pthread_join(p->th[i], NULL);
+    pthread_mutex_destroy(&p->m);
+    pthread_cond_destroy(&p->go);
+    pthread_cond_destroy(&p->done);
+    for (i = 0; i < PAR_MAX_THREADS; i++) {
+        free(p->lens[i]);
+        free(p->con[i]);
+    }
+    free(p->list);
+    free(p->starts);
+    free(p);
+    ps->pool = NULL;
+}
+
+typedef struct ParJob {
+    PktPool *pool;
+    const PktRef *list;
+    const Cur *starts;
+    uint32_t first[PAR_MAX_THREADS + 1];                   /* worker w reads packets first[w] .. first[w + 1] - 1 */
+    int nworkers;
+    PacketCtx pc[PAR_MAX_THREADS];
+    int failed[PAR_MAX_THREADS];
+} ParJob;
+
+static void par_worker(void *v, int tid)
+{
+    ParJob *j = (ParJob *)v;
+    PacketCtx *pc;
+    uint32_t i;
+    if (tid >= j->nworkers)
+        return;
+    pc = &j->pc[tid];
+    for (i = j->first[tid]; i < j->first[tid + 1]; i++) {
+        const PktRef *e = &j->list[i];
+        pc->at = &j->starts[i];
+        if (read_packet(pc, e->comp, e->res, (int)e->prec, e->layer) < 0 || pc->anomaly || pc->end_p != j->starts[i].end) {
+            j->failed[tid] = 1;
+            break;
+        }
+    }
+    j->pool->lens[tid] = pc->lens; j->pool->lens_cap[tid] = pc->lens_cap;
+    j->pool->con[tid] = pc->con; j->pool->con_cap[tid] = pc->con_cap;
+}
+
+static int tile_reads_in_parallel(const J2kParser *ps, const TileHdr *t)
+{
+    return ps->packet_threads > 1 && !ps->seq_only && !ps->has_ppm && !t->has_ppt &&
+           t->nplt >= 16 && !t->plt_bad && !t->plt_open && t->cod[0].layers == 1;
+}
+
+/* `list`: the tile's packets in order (the walker in list mode).  0, T2_AGAIN_SEQUENTIAL, or < 0 (out of memory) */
+static int read_tile_parallel(J2kParser *ps, TileHdr *t, int tileno, PktPool *pool, uint32_t n)
+{
+    ParJob *job;
+    Cur bodies[CS_MAX_TPARTS], c;
+    uint64_t total = 0, acc = 0;
+    uint32_t i, each, need;
+    int part = 0, w, nworkers, failed = 0;
+
+    if (n != t->nplt)
+        return T2_AGAIN_SEQUENTIAL;
+    if (pool->starts_cap < n) {
+        Cur *ns = (Cur *)realloc(pool->starts, (size_t)n * sizeof *ns);
+        if (!ns)
+            return HTJ2K_ERR_ENOMEM;
+        pool->starts = ns;
+        pool->starts_cap = n;
+    }
+    /* where the packets start: the tile-part bodies one after the other, as body_stream() walks them */
+    for (i = 0; i < CS_MAX_TPARTS; i++)
+        bodies[i] = t->part[i].body;
+    c = bodies[0];
+    for (i = 0; i < n; i++) {
+        while (!cur_left(&c) && part < CS_MAX_TPARTS - 1)
+            c = bodies[++part];
+        if (t->plt[i] > (uint32_t)cur_left(&c))
+            return T2_AGAIN_SEQUENTIAL;
+        pool->starts[i].p = c.p; pool->starts[i].end = c.p + t->plt[i]; pool->starts[i].base = c.base;
+        c.p += t->plt[i];
+        bodies[part] = c;
+        total += t->plt[i];
+    }
+
+    job = (ParJob *)calloc(1, sizeof *job);
+    if (!job)
+        return HTJ2K_ERR_ENOMEM;
+    nworkers = pool->nth + 1;
+    if ((uint32_t)nworkers > n / 8)
+        nworkers = (int)(n / 8) ? (int)(n / 8) : 1;
+    job->pool = pool; job->list = pool->list; job->starts = pool->starts; job->nworkers = nworkers;
+    /* runs of about equal bytes: a run starts at the packet whose middle is past the run's share */
+    for (i = 0, w = 0; i < n && w < nworkers; i++) {
+        if ((2 * acc + t->plt[i]) * (uint64_t)nworkers >= 2 * total * (uint64_t)w)
+            job->first[w++] = i;
+        acc += t->plt[i];
+    }
+    while (w <= nworkers)
+        job->first[w++] = n;
+    job->first[nworkers] = n;
+    /* every worker chains code-block pieces out of a slice of the table of its own; the table does not move meanwhile */
+    each = 4096 + 2 * (ps->geo.nblk / (uint32_t)nworkers);
+    need = ps->nsegs + (uint32_t)nworkers * each;
+    if (ps->segs_cap < need) {
+        SegNode *ns = (SegNode *)realloc(ps->segs, (size_t)need * sizeof *ns);
+        if (!ns) {
+            free(job);
+            return HTJ2K_ERR_ENOMEM;
+        }
+        ps->segs = ns;
+        ps->segs_cap = need;
+    }
+    for (w = 0; w < nworkers; w++) {
+        PacketCtx *pc = &job->pc[w];
+        pc->ps = ps; pc->tile = t; pc->tileno = tileno;
+        pc->quiet = 1;
+        pc->arena_next = ps->nsegs + (uint32_t)w * each;
+        pc->arena_limit = pc->arena_next + each;
+        pc->lens = pool->lens[w]; pc->lens_cap = pool->lens_cap[w];
+        pc->con = pool->con[w]; pc->con_cap = pool->con_cap[w];
+    }
+    pool_run(pool, par_worker, job, nworkers);
+    for (w = 0; w < nworkers; w++)
+        failed |= job->failed[w];
+    free(job);
+    if (failed)
+        return T2_AGAIN_SEQUENTIAL;
+    ps->nsegs = need;
+    for (i = 0; i < CS_MAX_TPARTS; i++)
+        t->part[i].body = bodies[i];
+    ps->g = c;
+    ps->parallel_tiles++;
+    return 0;
+}
+
+static int walk_tile(J2kParser *ps, TileHdr *t, PacketWalk *pw)
+{
     PocVolume whole;
     int i, ret = HTJ2K_ERR_BUG;
-
-    if (ps->geo.tile_err[tileno] < 0)
-        return ps->geo.tile_err[tileno];
-    memset(&pc, 0, sizeof pc);
-    pc.ps = ps; pc.tile = t; pc.tileno = tileno;
-    pc.lens = ps->scratch_lens; pc.lens_cap = ps->scratch_lens_cap;
-    pc.con = (Contribution *)ps->scratch_con; pc.con_cap = ps->scratch_con_cap;
-    memset(&pw, 0, sizeof pw);
-    pw.pc = &pc;
-
     if (t->poc.n) {
         for (i = 0; i < t->poc.n; i++) {
             PocVolume v = t->poc.v[i];
             v.lye = (uint16_t)min32(v.lye, t->cod[0].layers);
             v.ce = (uint16_t)min32(v.ce, ps->ncomp);
-            pw.vol = &v;
-            pw.order = v.order;
+            pw->vol = &v;
+            pw->order = v.order;
             ret = 0;
             if (v.order <= 4) {
-                pw.axes = nesting[v.order];
-                ret = walk(&pw, 0);
+                pw->axes = nesting[v.order];
+                ret = walk(pw, 0);
             }
             if (ret < 0)
                 break;
@@ -1265,14 +1563,55 @@ int t2_read_tile_packets(J2kParser *ps, int tileno)
     } else {
         whole.rs = 0; whole.cs = 0; whole.lye = t->cod[0].layers; whole.re = 33;
         whole.ce = (uint16_t)ps->ncomp; whole.order = t->cod[0].order;
-        pw.vol = &whole;
-        pw.order = whole.order;
+        pw->vol = &whole;
+        pw->order = whole.order;
         ret = 0;
         if (whole.order <= 4) {
-            pw.axes = nesting[whole.order];
-            ret = walk(&pw, 0);
+            pw->axes = nesting[whole.order];
+            ret = walk(pw, 0);
         }
     }
+    return ret;
+}
+
+/* all packets of a tile (jpeg2000_decode_packets, jpeg2000dec.c:1835-1869) */
+int t2_read_tile_packets(J2kParser *ps, int tileno)
+{
+    TileHdr *t = &ps->tile[tileno];
+    PacketCtx pc;
+    PacketWalk pw;
+    int ret;
+
+    if (ps->geo.tile_err[tileno] < 0)
+        return ps->geo.tile_err[tileno];
+    memset(&pc, 0, sizeof pc);
+    pc.ps = ps; pc.tile = t; pc.tileno = tileno;
+    memset(&pw, 0, sizeof pw);
+    pw.pc = &pc;
+
+    if (tile_reads_in_parallel(ps, t)) {
+        PktPool *pool = pool_get_threads(ps, ps->packet_threads);
+        if (pool && pool->nth > 0) {
+            pc.quiet = 1;
+            pw.list_mode = 1;
+            pw.list = pool->list; pw.list_cap = pool->list_cap;
+            ret = walk_tile(ps, t, &pw);
+            pool->list = pw.list; pool->list_cap = pw.list_cap;
+            if (ret == HTJ2K_ERR_ENOMEM)
+                return ret;
+            if (ret < 0 || pc.anomaly)
+                return T2_AGAIN_SEQUENTIAL;                /* (the list-making has marked precincts as read) */
+            ret = read_tile_parallel(ps, t, tileno, pool, pw.nlist);
+            if (ret)
+                return ret;
+            cur_skip(&ps->g, 2);                           /* EOC, or the next tile-part's SOT: not looked at */
+            return 0;
+        }
+    }
+
+    pc.lens = ps->scratch_lens; pc.lens_cap = ps->scratch_lens_cap;
+    pc.con = (Contribution *)ps->scratch_con; pc.con_cap = ps->scratch_con_cap;
+    ret = walk_tile(ps, t, &pw);
     ps->scratch_lens = pc.lens; ps->scratch_lens_cap = pc.lens_cap;
     ps->scratch_con = pc.con; ps->scratch_con_cap = pc.con_cap;
     if (ret < 0)

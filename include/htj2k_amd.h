@@ -232,6 +232,10 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
+ *   "packet_threads" 1 (default) .. 16: a frame that is parsed on its own (htj2k_decode, jobs of one frame) has the packets
+ *                 of every tile with a complete PLT packet-length list, one quality layer and no PPM / PPT read by this many
+ *                 threads; the plan is the same, and any disagreement between the list and the packets sends the frame through
+ *                 the sequential reader (csrc/j2k_tier2.c: read_tile_parallel)
  *   "ht_multi"    1 (default): jobs with 32-bit sub-bands whose HT blocks all are cleanup-only, at most 64 columns wide,
  *                 without ROI shift and of one transform decode 2 or 4 blocks per wavefront (k_ht_decode_multi); 0: one
  *                 block per wavefront, a lane per sample column

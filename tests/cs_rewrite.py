@@ -92,7 +92,7 @@ class Stream:
             if packed == "ppm":
                 ppm_data += struct.pack(">I", len(heads)) + heads
             if plt:
-                lens = b""
+                lens, z = b"", 0
                 for p in packets:
                     n = len(p[0]) + len(p[2]) + (0 if packed else len(p[1]))
                     groups = [n & 0x7F]
@@ -100,8 +100,11 @@ class Stream:
                     while n:
                         groups.insert(0, 0x80 | (n & 0x7F))
                         n >>= 7
+                    if len(lens) + len(groups) > 60000:            # a marker segment holds 65 535 bytes: the list goes on in the next
+                        hdr.append((PLT, bytes([z & 255]) + lens))
+                        lens, z = b"", z + 1
                     lens += bytes(groups)
-                hdr.append((PLT, b"\x00" + lens))
+                hdr.append((PLT, bytes([z & 255]) + lens))
             body = b"".join(p[0] + (b"" if packed else p[1]) + p[2] for p in packets)
             h = b"".join(seg(c, pl) for c, pl in hdr)
             psot = 12 + len(h) + 2 + len(body)
@@ -145,6 +148,7 @@ def variants(cs, ht):
     three = lambda isot, n: [n // 3, n // 3, n - 2 * (n // 3)] if n >= 3 else [n]
     ones = lambda isot, n: [1] * min(n, 31) + ([n - 31] if n > 31 else [])
     out.append(("same", s.build()))
+    out.append(("plt", s.build(plt=True)))
     out.append(("tp3_tlm_plt", s.build(parts_of=three, tlm=True, plt=True)))
     out.append(("tp_each_packet", s.build(parts_of=ones, plt=True)))
     out.append(("tp3_interleaved", s.build(parts_of=three, interleave=True, tlm=True)))

@@ -3,7 +3,9 @@
  * same packets: same return code, and for accepted packets the same plan -- stream facts, tile-component
  * table, block table, byte pool, LDS sizing figures.
  *
- *   plan_diff [-m N] [-s SEED] [-v] ORACLE_SO FILE...
+ *   plan_diff [-m N] [-s SEED] [-t THREADS] [-v] ORACLE_SO FILE...
+ *      -t: the product's parsers read the packets of tiles with a usable PLT list on THREADS threads
+ *          (j2k_parser_set_packet_threads); the plans must not change, and "parallel tiles" says how many tiles took that way
  *      every FILE is parsed as it is with reduction_factor 0..2 and bitexact 0/1, then N mutations of it
  *      (truncation, byte and bit damage, header-only damage) with random options.
  *   A FILE named *.list holds one path per line.
@@ -177,13 +179,15 @@ static void one_file(const char *path, J2kParser *mine, OrcParser *theirs, int i
 
 int main(int argc, char **argv)
 {
-    int iters = 0, a = 1;
+    int iters = 0, a = 1, threads = 0;
+    uint32_t ptiles = 0, pretries = 0, lt = 0, lr = 0;
     void *h;
     J2kParser *mine;
     OrcParser *theirs;
     while (a < argc && argv[a][0] == '-') {
         if (!strcmp(argv[a], "-m") && a + 1 < argc) { iters = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "-s") && a + 1 < argc) { rs = (uint32_t)strtoul(argv[a + 1], NULL, 0); a += 2; }
+        else if (!strcmp(argv[a], "-t") && a + 1 < argc) { threads = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "-v")) { verbose = 1; a++; }
         else break;
     }
@@ -197,6 +201,10 @@ int main(int argc, char **argv)
     mine = j2k_parser_new();
     lazy = j2k_parser_new();
     j2k_parser_set_gather(lazy, 0);
+    if (threads > 1) {
+        j2k_parser_set_packet_threads(mine, threads);
+        j2k_parser_set_packet_threads(lazy, threads);
+    }
     theirs = o_new();
     for (; a < argc; a++) {
         size_t L = strlen(argv[a]);
@@ -213,6 +221,9 @@ int main(int argc, char **argv)
         }
     }
     printf("plan_diff: %ld parses, %ld accepted, %ld differences\n", n_parse, n_ok, n_diff);
+    j2k_parser_parallel_stats(mine, &ptiles, &pretries);
+    j2k_parser_parallel_stats(lazy, &lt, &lr);
+    printf("plan_diff: parallel tiles %u, sequential retries %u\n", ptiles + lt, pretries + lr);
     j2k_parser_free(mine);
     j2k_parser_free(lazy);
     o_free(theirs);

@@ -462,6 +462,35 @@ def test_multi_block_kernel_matches_the_column_kernel_and_the_oracle(dec, orc):
     assert {1, 2, 4} <= seen, seen
 
 
+def test_plt_streams_decode_the_same_with_packet_threads(dec, orc):
+    """knob packet_threads: a frame parsed on its own has the packets of tiles with a PLT list read by several threads;
+    same frames as without, as the oracle's, for every container variant of a stream with many packets"""
+    import cs_rewrite
+    img = streams._img(640, 480, 3, 8, 31)
+    cs = vecgen.encode(img, sop=True, eph=True, mct=1, nlevels=4, prec=[(7, 7), (6, 6)], cb=(5, 5))
+    try:
+        for vn, data in cs_rewrite.variants(cs, True):
+            data = bytes(data)
+            if "ppm_tp3" in vn:                              # (a reference quirk decodes this one differently: tests/test_plan_equality.py)
+                continue
+            try:
+                info_o, planes_o, _ = orc.decode(data)
+            except oracle.DecodeError:                       # (more tile-parts than the reference takes: both must refuse)
+                planes_o = None
+            for th in (1, 4):
+                dec.set_int("packet_threads", th)
+                if planes_o is None:
+                    with pytest.raises(Exception):
+                        dec.decode(data)
+                    continue
+                info, planes, consumed, st = dec.decode(data)
+                assert st.n_block_errors == 0, vn
+                for a, b in zip(planes, planes_o):
+                    assert np.array_equal(a, b), (vn, th)
+    finally:
+        dec.set_int("packet_threads", 1)
+
+
 def test_coef16_is_not_used_where_it_does_not_apply(dec, orc):
     """odd geometry, 16-bit samples (M_b > 15), 9/7, refinement passes, Part-1 blocks, staged runs: int32 sub-bands as before"""
     for name in ("rgb_mct", "gray16", "rgb_97_ict", "rgb_3passes_cb32", "p1_rgb_mct", "gray_l5_cb64"):

@@ -36,24 +36,28 @@ def plan_diff(tmp_path_factory):
     d = tmp_path_factory.mktemp("plan_diff")
     exe = d / "plan_diff"
     srcs = [os.path.join(HERE, "native", "plan_diff.c")] + [os.path.join(CSRC, f) for f in ("j2k_syntax.c", "j2k_tier2.c", "j2k_plan.c")]
-    base = ["gcc", "-g", "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", str(exe)] + srcs + ["-lm", "-ldl"]
+    base = ["gcc", "-g", "-std=gnu11", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", str(exe)] + srcs + ["-lm", "-ldl"]
     r = subprocess.run(base[:1] + ["-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] + base[1:],
                        capture_output=True, text=True)
     if r.returncode != 0:
         r = subprocess.run(base[:1] + ["-O2"] + base[1:], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
 
-    def run(files, mutations, seed=1, workdir=d):
+    def run(files, mutations, seed=1, workdir=d, threads=0):
         lst = workdir / ("corpus_%d.list" % abs(hash(tuple(files))))
         lst.write_text("\n".join(str(f) for f in files) + "\n")
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-        r = subprocess.run([str(exe), "-m", str(mutations), "-s", str(seed), ORACLE_SO, str(lst)], capture_output=True, text=True,
-                           env=env, timeout=1200)
+        r = subprocess.run([str(exe), "-m", str(mutations), "-s", str(seed), "-t", str(threads), ORACLE_SO, str(lst)], capture_output=True,
+                           text=True, env=env, timeout=1200)
         tail = (r.stdout[-3000:], r.stderr[-3000:])
         assert r.returncode == 0, tail
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("plan_diff:")][-1].split()
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("plan_diff:")]
+        line = lines[-2].split()
         parses, accepted, diffs = int(line[1]), int(line[3]), int(line[5])
         assert diffs == 0, tail
+        if threads:
+            par = lines[-1].replace(",", "").split()            # plan_diff: parallel tiles N sequential retries M
+            return parses, accepted, int(par[3]), int(par[6])
         return parses, accepted
     return run
 
@@ -107,6 +111,24 @@ def test_container_variants(plan_diff, tmp_path):
     assert len(files) > 100
     parses, accepted = plan_diff(files, 120)
     assert accepted > parses // 3
+
+
+def test_plt_streams_read_by_several_threads(plan_diff, tmp_path):
+    """with a PLT packet-length list (and one layer, no PPM / PPT) the packets of a tile are read by
+    several threads (j2k_tier2.c: read_tile_parallel).  Same plans, byte pools and return codes as the oracle's parser on
+    every container variant and on thousands of damaged copies (where the list and the packets disagree the frame is
+    parsed again the sequential way); the variants with a usable list must really have gone the parallel way."""
+    files = [_write(tmp_path, n + ".j2c", d) for n, d in rewritten_streams()]
+    big = vecgen.encode(streams._img(1024, 640, 3, 8, 21), sop=True, eph=True, mct=1, nlevels=5, prec=[(7, 7), (6, 6)], cb=(5, 5))
+    for vn, data in cs_rewrite.variants(big, True):
+        if "plt" in vn:
+            files.append(_write(tmp_path, "big." + vn + ".j2c", data))
+    parses, accepted, ptiles, retries = plan_diff(files, 150, seed=5, threads=4)
+    assert accepted > parses // 3
+    assert ptiles > 1000 and retries > 100, (ptiles, retries)
+    only_plt = [f for f in files if ".plt." in str(f) or "tlm_plt" in str(f)]
+    parses, accepted, ptiles, retries = plan_diff(only_plt, 0, threads=3)
+    assert ptiles >= 2 * len(only_plt) and retries == 0, (ptiles, retries, len(only_plt))
 
 
 def random_stream(rng, it):
