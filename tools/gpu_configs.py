@@ -8,7 +8,7 @@ import ffmpeg_ht_amd as m
 import vecgen
 
 def img(w, h, nc, depth, seed, dx=None):
-    out = vecgen.synth_image(w, h, nc, depth=depth, seed=seed, noise=8)
+    out = vecgen.synth_image(w, h, nc, depth=depth, seed=seed, noise=int(os.environ.get("NOISE", "8")))
     comps = list(out) if isinstance(out, (list, tuple)) else ([out[..., i] for i in range(nc)] if out.ndim == 3 else [out])
     if dx:
         comps = [c[:, ::dx[i]] for i, c in enumerate(comps)]
