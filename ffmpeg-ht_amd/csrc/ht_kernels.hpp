@@ -7,8 +7,8 @@
  * (jpeg2000dec.c:2279-2287).  How it computes it is not the reference's byte-at-a-time
  * bit buffers.  The work of a block splits by its dependence structure:
  *
- *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, SigProp, MagRef bytes) and the
- *                       head of k_ht_decode (MagSgn): four bytes per lane, per-byte bit counts
+ *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, SigProp, MagRef bytes: four bytes per lane) and the
+ *                       head of the MagSgn kernels (eight bytes per lane): per-byte bit counts
  *                       (7 after a 0xFF, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
  *                       >0x8F byte for the backward streams, :145-201), wave prefix sum -> bit
  *                       offset of the lane's chunk, ds_or into 32-bit words.
@@ -25,6 +25,8 @@
  *                       k_ht_decode_pair: the same for two blocks per wave with one lane per quad
  *                       (the quad-level work is not done twice), for jobs whose sub-bands are
  *                       stored as 16-bit samples (htj2k_device.hip: coef16).
+ *                       k_ht_decode_multi: a lane per quad and two or four blocks per wave for
+ *                       jobs with 32-bit sub-bands (all three dequantisers, refinement masks).
  *
  * k_ht_decode<false> is the first correct version (everything in one kernel, the serial stages on
  * lane 0), kept as a fallback and A/B reference; its LDS layout is HtLds.
@@ -54,7 +56,7 @@ struct HtLds {
 #define HT_VSTAGE_BYTES (64 * HT_VSTAGE_PITCH * 4)
 
 /* quad symbols of a block in d_qsym: rows padded to an even number of quads (k_ht_vlc emits two
- * per pass of its loop), the block rounded up to 16 words (its lanes flush 64-byte chunks) */
+ * per pass of its loop), the block rounded up to 16 symbols (its lanes flush 32-byte chunks) */
 /* One quad symbol is 16 bits: bits 0-7 four 2-bit fields, field n = rho_n + e_k,n + e_1,n of sample n (e_1 is only
  * ever set where e_k is, e_k where rho is: 0 = not significant, 1 = significant, 2 = + known exponent bound, 3 = + known
  * MSB), bits 8-15 the U-VLC value u (at most 2 + 5 + 31 + 4 * 15).  (Until round 2 a dword: rho | e_k << 4 | e_1 << 8 |
