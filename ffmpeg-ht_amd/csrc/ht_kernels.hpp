@@ -1652,9 +1652,6 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
         top &= wmask; bot &= wmask;
         if (2 * qy + 1 >= h) bot = 0;
     };
-    auto win = [](uint64_t x, int j) -> uint32_t {                   /* bits j-1, j, j+1 */
-        return (uint32_t)(j ? (x >> (j - 1)) : (x << 1)) & 7u;
-    };
 
     uint64_t a_top, a_bot;
     quad_rows(0, a_top, a_bot);
@@ -1666,34 +1663,54 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
         const uint64_t S0 = a_top, S1 = a_bot, S2 = b_top, S3 = b_bot, S4 = c_top;
         uint64_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0, Q0 = 0, Q1 = 0, Q2 = 0, Q3 = 0;
         const int gh = min(4, h - i0);
-        for (int j0 = 0; j0 < w; j0 += 4) {
-            if (sp.cnt <= 32) sp.top_up();                             /* a 4x4 group takes at most 32 bits */
-#define HT_SIGPROP_SAMPLE(ii, SC, RC, UP, DN)                                                           \
-            if (ii < gh && !((SC >> j) & 1)) {                                                            \
-                const bool below_ok = !causal || ii != gh - 1;                                            \
-                const uint32_t mbr = win(UP, j) | (win(SC | RC, j) & 5u) | (below_ok ? win(DN, j) : 0u);  \
-                if (mbr && sp.get()) RC |= 1ull << j;                                                     \
-            }
+        /* SigProp (:1016-1100).  A sample is a candidate when the cleanup pass left it insignificant and one of its eight
+         * neighbours is significant.  The neighbours split into what the cleanup pass decided -- per row one 64-bit mask
+         * T_i, made once per stripe: the rows above and below smeared by a column either way, the row itself shifted --
+         * and what this pass has decided so far, which at column j is only column j - 1 (all rows: `rprev`) and the rows
+         * above in column j itself (`rcur`): two 4-bit values.  The masks are shifted along with the column, so that a
+         * sample costs a handful of 32-bit operations instead of three variable 64-bit shifts. */
+        {
+            auto smear = [](uint64_t x) -> uint64_t { return x | (x << 1) | (x >> 1); };
+            const bool dn0 = !causal || gh != 1, dn1 = !causal || gh != 2, dn2 = !causal || gh != 3, dn3 = !causal || gh != 4;
+            uint64_t s0 = S0, s1 = S1, s2 = S2, s3 = S3;
+            uint64_t T0 = smear(Mup) | (S0 << 1) | (S0 >> 1) | (dn0 ? smear(S1) : 0ull);
+            uint64_t T1 = smear(S0) | (S1 << 1) | (S1 >> 1) | (dn1 ? smear(S2) : 0ull);
+            uint64_t T2 = smear(S1) | (S2 << 1) | (S2 >> 1) | (dn2 ? smear(S3) : 0ull);
+            uint64_t T3 = smear(S2) | (S3 << 1) | (S3 >> 1) | (dn3 ? smear(S4) : 0ull);
+            const uint32_t m0 = dn0 ? 7u : 3u, m1 = dn1 ? 7u : 3u, m2 = dn2 ? 7u : 3u, m3 = dn3 ? 7u : 3u;
+            uint32_t rprev = 0;
+            for (int j0 = 0; j0 < w; j0 += 4) {
+                uint32_t rc4[4] = { 0, 0, 0, 0 };
+                if (sp.cnt <= 32) sp.top_up();                         /* a 4x4 group takes at most 32 bits */
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int j = j0 + jj;
-                if (j < w) {
-                    HT_SIGPROP_SAMPLE(0, S0, R0, Mup, (S1 | R1))
-                    HT_SIGPROP_SAMPLE(1, S1, R1, (S0 | R0), (S2 | R2))
-                    HT_SIGPROP_SAMPLE(2, S2, R2, (S1 | R1), (S3 | R3))
-                    HT_SIGPROP_SAMPLE(3, S3, R3, (S2 | R2), S4)
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = j0 + jj;
+                    if (j < w) {
+                        const uint32_t RP = rprev << 1;                 /* bit k + 1: row k of column j - 1 */
+                        uint32_t rcur = 0;
+                        if (gh > 0 && !((uint32_t)s0 & 1u) && ((((uint32_t)T0 & 1u) | (RP & m0)) != 0) && sp.get()) rcur |= 1u;
+                        if (gh > 1 && !((uint32_t)s1 & 1u) && ((((uint32_t)T1 & 1u) | ((RP >> 1) & m1) | (rcur & 1u)) != 0) && sp.get()) rcur |= 2u;
+                        if (gh > 2 && !((uint32_t)s2 & 1u) && ((((uint32_t)T2 & 1u) | ((RP >> 2) & m2) | (rcur & 2u)) != 0) && sp.get()) rcur |= 4u;
+                        if (gh > 3 && !((uint32_t)s3 & 1u) && ((((uint32_t)T3 & 1u) | ((RP >> 3) & m3) | (rcur & 4u)) != 0) && sp.get()) rcur |= 8u;
+                        R0 |= (uint64_t)(rcur & 1u) << j; R1 |= (uint64_t)((rcur >> 1) & 1u) << j;
+                        R2 |= (uint64_t)((rcur >> 2) & 1u) << j; R3 |= (uint64_t)(rcur >> 3) << j;
+                        rc4[jj] = rcur;
+                        rprev = rcur;
+                        s0 >>= 1; s1 >>= 1; s2 >>= 1; s3 >>= 1;
+                        T0 >>= 1; T1 >>= 1; T2 >>= 1; T3 >>= 1;
+                    }
                 }
-            }
-#undef HT_SIGPROP_SAMPLE
-            /* signs of the samples this group made significant, same order (:1085-1100) */
+                /* signs of the samples this group made significant, same order (:1085-1100) */
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int j = j0 + jj;
-                if (j < w) {
-                    if ((R0 >> j) & 1) G0 |= (uint64_t)sp.get() << j;
-                    if ((R1 >> j) & 1) G1 |= (uint64_t)sp.get() << j;
-                    if ((R2 >> j) & 1) G2 |= (uint64_t)sp.get() << j;
-                    if ((R3 >> j) & 1) G3 |= (uint64_t)sp.get() << j;
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = j0 + jj;
+                    const uint32_t r = rc4[jj];
+                    if (j < w && r) {
+                        if (r & 1u) G0 |= (uint64_t)sp.get() << j;
+                        if (r & 2u) G1 |= (uint64_t)sp.get() << j;
+                        if (r & 4u) G2 |= (uint64_t)sp.get() << j;
+                        if (r & 8u) G3 |= (uint64_t)sp.get() << j;
+                    }
                 }
             }
         }
@@ -1707,10 +1724,22 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
             }
         }
         uint64_t *o = out + 3 * i0;
-        o[0] = R0; o[1] = G0; o[2] = Q0;
-        if (gh > 1) { o[3] = R1; o[4] = G1; o[5] = Q1; }
-        if (gh > 2) { o[6] = R2; o[7] = G2; o[8] = Q2; }
-        if (gh > 3) { o[9] = R3; o[10] = G3; o[11] = Q3; }
+        if (gh > 3) {                                                  /* the stripe's 96 bytes as six 16-byte stores (a lane writes its own block:
+                                                                        * every store instruction of the wave is 64 scattered requests) */
+            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+            typedef u64x2 u64x2_a8 __attribute__((aligned(8)));
+            u64x2 v;
+            v.x = R0; v.y = G0; *(u64x2_a8 *)(o + 0) = v;
+            v.x = Q0; v.y = R1; *(u64x2_a8 *)(o + 2) = v;
+            v.x = G1; v.y = Q1; *(u64x2_a8 *)(o + 4) = v;
+            v.x = R2; v.y = G2; *(u64x2_a8 *)(o + 6) = v;
+            v.x = Q2; v.y = R3; *(u64x2_a8 *)(o + 8) = v;
+            v.x = G3; v.y = Q3; *(u64x2_a8 *)(o + 10) = v;
+        } else {
+            o[0] = R0; o[1] = G0; o[2] = Q0;
+            if (gh > 1) { o[3] = R1; o[4] = G1; o[5] = Q1; }
+            if (gh > 2) { o[6] = R2; o[7] = G2; o[8] = Q2; }
+        }
         Mup = S3 | R3;
         a_top = c_top; a_bot = c_bot;
     }
