@@ -88,6 +88,73 @@ def max_over_ranks(seconds):
     return float(t.item())
 
 
+def all_ranks(value):
+    """[value of rank 0, value of rank 1, ...] on every rank (a SUM all-reduce of one-hot vectors: the timing
+    bookkeeping, not a data-path collective)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(device_index, sysfs="/sys"):
+    """NUMA node of HIP device `device_index`, read from sysfs without touching the GPU: the KFD topology lists the
+    GPU nodes in the order the runtime enumerates them (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES index lists are
+    honoured), each with its DRM render minor, whose PCI device has a numa_node.  None when any of it is missing."""
+    try:
+        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for name in sorted(os.listdir(base), key=int):
+            props = dict(l.split()[:2] for l in open(os.path.join(base, name, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            vis = os.environ.get(var)
+            if vis:
+                gpus = [gpus[int(x)] for x in vis.split(",") if x.strip().isdigit() and int(x) < len(gpus)]
+        minor = gpus[device_index]
+        node = int(open(os.path.join(sysfs, "class/drm/renderD%d/device/numa_node" % minor)).read())
+        return node if node >= 0 else None
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+
+
+def bind_near_gpu(device_index, sysfs="/sys"):
+    """Before the first GPU call: restrict this process (and the threads it will start -- parser workers, staging
+    copies, the pipeline) to the CPUs of the NUMA node its GPU hangs off, so that page-locked buffers are first
+    touched there.  A plain sched_setaffinity call, nothing is re-executed.  Returns what was done, for the JSON line."""
+    try:
+        have = os.sched_getaffinity(0)
+    except AttributeError:
+        return {"numa_node": None, "bound": False}
+    node = gpu_numa_node(device_index, sysfs)
+    if node is None:
+        return {"numa_node": None, "bound": False, "cpus": len(have)}
+    try:
+        near = _cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read()) & have
+    except (OSError, ValueError):
+        near = set()
+    if len(near) < 4 or near == have:                     # nothing to gain, or a cgroup that put us elsewhere
+        return {"numa_node": node, "bound": False, "cpus": len(have)}
+    os.sched_setaffinity(0, near)
+    return {"numa_node": node, "bound": True, "cpus": len(near)}
+
+
 def make_streams(nstreams, rank, with_images=False):
     """distinct synthetic 4K RGB frames (BASELINE.md section 3 generator) -> HTJ2K codestreams"""
     import vecgen
@@ -209,16 +276,18 @@ def part1_leg(dec, nframes, with_cpu):
     return out
 
 
-def stream240_leg(dec, m, rank, world, nframes, barrier):
+def stream240_leg(dec, m, rank, world, nframes, barrier, min_frames_per_rank=1200, nwarm_distinct=6):
     """BASELINE configs[4]: a stream of `nframes` distinct 4K 10-bit lossless RGB frames (-> rgb48, samples << 6), frame
     i on rank i mod world, every rank's share through the asynchronous pipeline: packets in pageable host memory ->
     frames in page-locked host memory.  Host parsing, staging, PCIe both ways and the kernels are all inside the clock.
-    Returns (seconds on this rank, frames of this rank, parity)."""
+    A rank cycles through its share until it has decoded at least `min_frames_per_rank` frames (30 frames per rank at
+    N = 8 would be 30 ms of clock: thread wake-ups, not throughput), and the pipeline is warmed up on OTHER frames than
+    the timed ones.  Returns (seconds on this rank, frames this rank decoded inside the clock, parity, ...)."""
     import concurrent.futures
     import numpy as np
     import vecgen
     mine = shard_frames(nframes, rank, world)
-    workers = max(1, min(16, host_cores() // max(world, 1)))
+    workers = max(1, min(16, host_cores() // (1 if os.environ.get("HTJ2K_BENCH_BOUND") == "1" else max(world, 1))))
 
     def make(i):                                           # ctypes releases the GIL inside the encoder
         img = vecgen.synth_image(WIDTH, HEIGHT, NCOMP, depth=10, seed=1000 + i, noise=20)
@@ -227,20 +296,24 @@ def stream240_leg(dec, m, rank, world, nframes, barrier):
     t0 = time.perf_counter()
     with concurrent.futures.ThreadPoolExecutor(workers) as ex:
         made = list(ex.map(make, mine))
+        warm_made = list(ex.map(make, [100000 + nwarm_distinct * rank + k for k in range(nwarm_distinct)]))
     t_enc = time.perf_counter() - t0
     keep = {mine[k]: im for k, (_, im) in enumerate(made) if im is not None}
     nbytes = sum(len(d) for d, _ in made)
     info0 = dec.probe(made[0][0])
     pkts = [m.packet(d) for d, _ in made]                  # padded buffers, sent by reference (htj2k_pipe_send_ref)
-    del made
+    warm_pkts = [m.packet(d) for d, _ in warm_made]
+    del made, warm_made
+    reps = max(1, -(-min_frames_per_rank // len(pkts)))
+    total = reps * len(pkts)
     pinned, ptrs = dec.alloc_frame_pinned(info0)
     first = last = None
     pipe = dec.pipe(batch=8, depth=3)
-    # warm-up outside the clock: buffers of all jobs get allocated
-    warm = min(24, len(pkts))
+    # warm-up outside the clock on frames that are not part of the stream: buffers of all jobs get allocated
+    warm = 24
     sent = got = 0
     while got < warm:
-        while sent < warm and pipe.send(pkts[sent]):
+        while sent < warm and pipe.send(warm_pkts[sent % len(warm_pkts)]):
             sent += 1
         if sent == warm:
             pipe.flush()
@@ -249,28 +322,28 @@ def stream240_leg(dec, m, rank, world, nframes, barrier):
     barrier()
     t0 = time.perf_counter()
     sent = got = 0
-    while got < len(pkts):
-        while sent < len(pkts) and pipe.send(pkts[sent]):
+    while got < total:
+        while sent < total and pipe.send(pkts[sent % len(pkts)]):
             sent += 1
-        if sent == len(pkts):
+        if sent == total:
             pipe.flush()
         if pipe.receive(into=pinned) is None:
             break
         if got == 0:
             first = pinned[0][0].copy()
-        if got == len(pkts) - 1:
+        if got == total - 1:
             last = pinned[0][0].copy()
         got += 1
     dt = time.perf_counter() - t0
     barrier()
     pipe.close()
-    ok = got == len(pkts)
+    ok = got == total
     for fr, idx in ((first, mine[0]), (last, mine[-1])):
         img = keep.get(idx)
         ok = ok and fr is not None and img is not None and \
             np.array_equal(fr.view(np.uint16).reshape(HEIGHT, WIDTH, 3) >> 6, np.stack(img, -1))
     dec.free_frame_pinned(ptrs)
-    return dt, len(pkts), ok, t_enc, nbytes
+    return dt, total, ok, t_enc, nbytes / len(pkts), reps
 
 
 def main():
@@ -292,6 +365,9 @@ def main():
                     "every kernel launch in the trace is then a batch launch)")
     ap.add_argument("--stream240", type=int, default=240, metavar="FRAMES",
                     help="frames of the configs[4] end-to-end leg (all ranks; 0 = skip; skipped with --no-e2e)")
+    ap.add_argument("--stream240-min-frames", type=int, default=1200, metavar="N", dest="stream240_min_frames",
+                    help="every rank cycles through its share of the stream240 frames until it has decoded this many "
+                         "(>= 1 s of clock per rank)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -307,11 +383,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU" % (args.gpus, world))
-    import numpy as np
-    import torch
     # rehearsal knobs (never set by the driver): several ranks on the one GPU of a test box, over gloo
     backend = os.environ.get("HTJ2K_BENCH_BACKEND", "nccl")
     device = int(os.environ["HTJ2K_BENCH_DEVICE"]) if "HTJ2K_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
+    # before anything touches the GPU (or allocates page-locked memory): stay on the CPUs next to this rank's GPU
+    affinity = bind_near_gpu(device) if world > 1 and os.environ.get("HTJ2K_BENCH_BIND", "1") != "0" else {"bound": False}
+    if affinity.get("bound"):
+        os.environ["HTJ2K_BENCH_BOUND"] = "1"
+    import numpy as np
+    import torch
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device)
@@ -368,7 +448,9 @@ def main():
     for job in jobs:
         job.wait()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_here)
+    rank_seconds = all_ranks(elapsed_here)
 
     frames_total = args.steps * args.batch * world
     value = frames_total * WIDTH * HEIGHT / elapsed / 1e6
@@ -421,6 +503,7 @@ def main():
     c16, ll16 = bool(rjob.coef16()), rjob.ll16() == 1
     if own_rjob:
         rjob.free()
+    copy_measured = dec.copy_bench(512, 10) if rank == 0 else 0.0
     ht_ms, idwt_ms, pack_ms = rf["ht"], rf["idwt"], rf["pack"]
     idwt_launch_ms, idwt_launch_bytes, idwt_launch_hbm, nlaunch = rf["lms"], rf["lby"], rf["lhb"], rf["n"]
     rsteps = rf["steps"]
@@ -473,17 +556,23 @@ def main():
     stream240 = None
     if args.stream240 > 0 and not args.no_e2e:
         n240 = max(args.stream240, world)
-        dt, mine, ok, t_enc, nbytes = stream240_leg(dec, m, rank, world, n240, barrier)
+        dt, mine, ok, t_enc, bytes_per_frame, reps = stream240_leg(dec, m, rank, world, n240, barrier,
+                                                                   min_frames_per_rank=args.stream240_min_frames)
         dt_all = max_over_ranks(dt)
-        if not ok:
+        per_rank_s = all_ranks(dt)
+        decoded = sum(all_ranks(mine))
+        if min(all_ranks(1.0 if ok else 0.0)) < 1.0:
             sys.exit("bench.py: stream240 frames do not match their sources")
-        stream240 = {"value": round(n240 * WIDTH * HEIGHT / dt_all / 1e6, 1), "unit": "Mpixel/s", "frames": n240,
-                     "frames_this_rank": mine, "seconds": round(dt_all, 4), "parity_checked": True,
+        stream240 = {"value": round(decoded * WIDTH * HEIGHT / dt_all / 1e6, 1), "unit": "Mpixel/s", "frames": n240,
+                     "frames_decoded": int(decoded), "passes_over_own_share_rank0": reps,
+                     "frames_this_rank": mine, "seconds": round(dt_all, 4),
+                     "seconds_per_rank": [round(x, 4) for x in per_rank_s], "parity_checked": True,
                      "workload": "configs[4]: %d distinct 3840x2160 10-bit RGB lossless 5/3 + RCT frames (rgb48 out), frame i on "
-                                 "rank i mod %d; pageable packets in -> page-locked frames out through htj2k_pipe (batches of 8, "
-                                 "3 in flight); host parsing + staging + PCIe + kernels inside the clock, max over ranks"
-                                 % (n240, world),
-                     "compressed_MB_per_frame": round(nbytes / max(mine, 1) / 1e6, 2),
+                                 "rank i mod %d, every rank cycling through its share until it has decoded >= %d frames (warm-up "
+                                 "on other frames); pageable packets in -> page-locked frames out through htj2k_pipe (batches of "
+                                 "8, 3 in flight); host parsing + staging + PCIe + kernels inside the clock, max over ranks"
+                                 % (n240, world, args.stream240_min_frames),
+                     "compressed_MB_per_frame": round(bytes_per_frame / 1e6, 2),
                      "encode_s_outside_the_clock": round(t_enc, 1)}
 
     if rank == 0:
@@ -501,9 +590,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int32 (int16 storage)" if c16 else "int32",
             "data": "synthetic",
             "parity_checked": True,
+            "seconds_per_rank": [round(x, 5) for x in rank_seconds],
+            "affinity": affinity,
             "config": {"workload": "configs[1]: 3840x2160 RGB 8-bit lossless 5/3 + RCT, 64x64 codeblocks, 5 levels, "
                                    "single tile, HT cleanup pass only; %d frames per step per GPU as %d concurrent "
                                    "jobs (HIP streams; the frame pipeline keeps that many in flight), device-resident input "
@@ -524,6 +615,11 @@ def main():
                          "algorithmic_GBps": round(algorithmic, 1),
                          "algorithmic_MB_per_launch": round(idwt_launch_bytes / max(nlaunch, 1) / 1e6, 3),
                          "copy_ceiling": COPY_CEILING_GBS,
+                         "copy_ceiling_measured": round(copy_measured, 1),
+                         "frac_of_copy_ceiling_measured": round(achieved / copy_measured, 4) if copy_measured > 0 else None,
+                         "copy_ceiling_note": "copy_ceiling: the guide's float4-copy figure; copy_ceiling_measured: htj2k_copy_bench "
+                                              "in this process on this device right after the roofline pass -- a kernel that only copies "
+                                              "512 MB to another 512 MB (about the bytes of one IDWT launch), best of three grid sizes",
                          "sub_bands_16bit": c16, "ll_bands_16bit": ll16,
                          "measured": "separate pass after the timed region: the same batch as one job, %d steps, every IDWT launch alone on the chip" % rsteps,
                          "note": "achieved / frac count the bytes the launches have to move through HBM (per sample: sub-bands "

@@ -73,7 +73,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_job_upload", "htj2k_job_run", "htj2k_job_download", "htj2k_job_wait", "htj2k_job_info",
            "htj2k_job_bytes_consumed", "htj2k_job_free", "htj2k_job_num_tilecomps", "htj2k_job_tilecomp_dims",
            "htj2k_job_read_plane", "htj2k_job_run_stages", "htj2k_job_stage_ms", "htj2k_idwt_plane",
-           "htj2k_idwt_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
+           "htj2k_idwt_bench", "htj2k_copy_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
            "htj2k_job_parse_batch", "htj2k_job_parse_batch_ex", "htj2k_job_num_frames", "htj2k_job_host_ms", "htj2k_job_frame_info", "htj2k_job_download_frame",
            "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16", "htj2k_job_ht_blocks_per_wave",
@@ -506,6 +506,12 @@ class Decoder:
         ms = ctypes.c_float()
         _check(self.L.htj2k_idwt_bench(self.h, w, h, levels, type_, nplanes, iters, ctypes.byref(ms)), "htj2k_idwt_bench")
         return ms.value
+
+    def copy_bench(self, mbytes=512, iters=10):
+        """GB/s (read + written) of a plain device-to-device copy kernel on this box: the measured copy ceiling"""
+        g = ctypes.c_float()
+        _check(self.L.htj2k_copy_bench(self.h, int(mbytes), int(iters), ctypes.byref(g)), "htj2k_copy_bench")
+        return g.value
 
     def mct(self, type_, p0, p1, p2):
         a, b, c = (np.ascontiguousarray(x).copy() for x in (p0, p1, p2))

@@ -1854,6 +1854,53 @@ extern "C" int htj2k_idwt_bench(htj2k_ctx *c, int w, int h, int levels, int type
     return 0;
 }
 
+/* Calibration for the roofline figures: what a kernel that does nothing but move bytes reaches on THIS device, so
+ * that a box whose memory system copies at 5.1 TB/s is not read as a kernel at 0.55 of 8 TB/s.  A grid-stride copy of
+ * 16-byte elements, `mbytes` MB read and as many written per launch; the launch shapes of tools/ubench/membw.hip,
+ * the best of them is returned (GB/s, read + written). */
+__global__ void __launch_bounds__(256) k_copy_linear(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int htj2k_copy_bench(htj2k_ctx *c, int mbytes, int iters, float *gbps)
+{
+    if (!c || mbytes <= 0 || mbytes > 8192 || iters <= 0 || !gbps) return HTJ2K_ERR_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)mbytes * 1000000 / 16;
+    DevBuf src, dst;
+    int r;
+    if ((r = src.ensure(n * 16)) < 0 || (r = dst.ensure(n * 16)) < 0) { src.release(); dst.release(); return r; }
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(src.p, 1, n * 16, s);
+    float best = 0;
+    const int grids[3] = { 8192, 65536, 262144 };
+    for (int g = 0; g < 3 && e == hipSuccess; g++) {
+        for (int i = 0; i < 2; i++)
+            hipLaunchKernelGGL(k_copy_linear, dim3(grids[g]), dim3(256), 0, s, (const uint4 *)src.p, (uint4 *)dst.p, n);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters; i++)
+            hipLaunchKernelGGL(k_copy_linear, dim3(grids[g]), dim3(256), 0, s, (const uint4 *)src.p, (uint4 *)dst.p, n);
+        (void)hipEventRecord(e1, s);
+        e = hipStreamSynchronize(s);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0) best = std::max(best, (float)(2.0 * n * 16 * iters / (ms * 1e-3) / 1e9));
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    src.release(); dst.release();
+    if (e != hipSuccess) { clog(c, LOG_ERROR, "HIP error %s in htj2k_copy_bench\n", hipGetErrorString(e)); return HTJ2K_ERR_EXTERNAL; }
+    *gbps = best;
+    return 0;
+}
+
 extern "C" int htj2k_mct_planes(htj2k_ctx *c, void *p0, void *p1, void *p2, int csize, int type)
 {
     if (!c || !p0 || !p1 || !p2 || csize <= 0 || type < 0 || type > 2) return HTJ2K_ERR_EINVAL;

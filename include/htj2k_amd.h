@@ -201,6 +201,10 @@ int  htj2k_idwt_plane(htj2k_ctx *ctx, void *plane, const int border[2][2],
  * `nplanes` identical-geometry planes and returns mean ms per iteration */
 int  htj2k_idwt_bench(htj2k_ctx *ctx, int w, int h, int decomp_levels, int type,
                       int nplanes, int iters, float *ms_per_iter);
+/* calibration for the roofline figures (no counterpart in the reference): GB/s, read + written, of a kernel that only
+ * copies `mbytes` MB of device memory per launch (16-byte elements, grid-stride; best of three launch shapes) on the
+ * context's device -- the ceiling a bandwidth-bound kernel can be held against on this particular box */
+int  htj2k_copy_bench(htj2k_ctx *ctx, int mbytes, int iters, float *gbps);
 /* Jpeg2000DSPContext.mct_decode[type] (jpeg2000dsp.c:43-91) on host planes */
 int  htj2k_mct_planes(htj2k_ctx *ctx, void *p0, void *p1, void *p2, int csize, int type);
 
