@@ -243,53 +243,90 @@ __device__ __forceinline__ uint32_t ht_dpp_right(uint32_t v)       /* lane i <- 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
 }
 
-/* MagSgn bytes -> plain LSB-first bit array in LDS (jpeg2000htdec.c:207-221): a byte that follows
- * 0xFF advances the stream by 7 bits but is ORed in whole.  Eight bytes per lane and pass: the
- * lane's bytes are merged into one chunk of 56..64 stream bits, a wave prefix sum of the chunk
- * lengths gives its bit offset, three ds_or place it.  D is 16-byte aligned (j2k_plan.c lays the
- * block data out that way); ms[] must be zero up to the word after the last stream bit.
- * Returns the number of stream bits. */
-/* one pass over 512 bytes, eight per lane (`dq` = dwords 2 (p0 + lane), 2 (p0 + lane) + 1 of the stream; anything where
- * the stream has ended): the prefix sum, the carry and the LDS ORs are per pass, so eight bytes per lane are ~30 % fewer
- * instructions per byte than four (k_ht_decode_pair 1.43 -> 1.40 ms).  Which
- * bytes follow an 0xFF comes out of one SWAR test per dword (the dword shifted up by one byte with the byte before it
- * in front; x == 0xFF exactly when bit 7 is set and the low seven bits carry into it when 1 is added). */
-__device__ __forceinline__ void ht_unstuff_magsgn_step8(uint2 dq, uint32_t p0, uint32_t Pcup, uint32_t *ms, int lane,
-                                                        uint32_t &base, uint32_t &carry)
+/* ---- un-stuffing, eight bytes per lane and pass ----
+ * A lane holds 64 raw stream bits `hi:lo` in read order (LSB first) and a flag at the top bit of every byte that
+ * carries 7 bits instead of 8.  Stuffed bytes are rare (one byte in 256 is an 0xFF), so instead of rebuilding the
+ * chunk byte by byte the flagged bits are squeezed out one at a time, top down, in two wave-level loops that run once
+ * or not at all on most passes; the rest -- bit counts, wave prefix sum, three LDS ORs -- is per pass.  (Round 2
+ * merged the eight bytes with per-byte shifts, ~110 VALU instructions per pass; this is ~50.)
+ *   OR_SEM = true : MagSgn (jpeg2000htdec.c:207-221): the byte behind an 0xFF is ORed in whole and the stream
+ *                   advances by 7 bits, so its top bit lands on the next byte's bit 0 (zero in a conforming stream);
+ *   OR_SEM = false: the flagged byte's top bit is dropped (SigProp :1016-1131, the backward VLC / MagRef streams
+ *                   :145-201).
+ * `nv` = stream bytes in this lane (0..8; bytes past them are zero and carry no flag).  `out` must be zero up to the
+ * word after the last stream bit. */
+template <bool OR_SEM>
+__device__ __forceinline__ void ht_squeeze_place(uint32_t lo, uint32_t hi, uint32_t fl, uint32_t fh, int nv,
+                                                 uint32_t *out, int lane, uint32_t &base)
 {
-    const uint32_t pi = p0 + lane;
-    const int nv = min(max((int)Pcup - (int)(pi * 8), 0), 8);           /* stream bytes in this lane's two dwords */
-    const int nl = min(nv, 4), nh = nv - nl;
-    uint32_t lo = nl > 0 ? dq.x : 0u, hi = nh > 0 ? dq.y : 0u;
-    if (nl < 4) lo &= nl ? (0xFFFFFFFFu >> (32 - 8 * nl)) : 0u;
-    if (nh < 4) hi &= nh ? (0xFFFFFFFFu >> (32 - 8 * nh)) : 0u;
-    uint32_t prev = ht_dpp_left(hi >> 24);
-    if (lane == 0) prev = carry;
-    carry = (uint32_t)__builtin_amdgcn_readlane((int)(hi >> 24), 63);   /* the last byte of this pass */
-    auto chunk = [](uint32_t dw, uint32_t before, int n, uint32_t &bits) -> uint32_t {
-        const uint32_t P = (dw << 8) | before;                          /* the bytes in front of b0 .. b3 */
-        const uint32_t ff = ((P & 0x7F7F7F7Fu) + 0x01010101u) & P & 0x80808080u;
-        const uint32_t f0 = (ff >> 7) & 1, f1 = (ff >> 15) & 1, f2 = (ff >> 23) & 1;
-        const uint32_t o1 = 8 - f0, o2 = o1 + 8 - f1, o3 = o2 + 8 - f2;
-        /* bytes past the stream are zero and are not counted: only the flags of the first n bytes */
-        const uint32_t fm = n >= 4 ? ff : (ff & (n ? (0xFFFFFFFFu >> (32 - 8 * n)) : 0u));
-        bits = 8u * (uint32_t)n - (uint32_t)__builtin_popcount(fm);
-        return (dw & 0xFF) | (((dw >> 8) & 0xFF) << o1) | (((dw >> 16) & 0xFF) << o2) | ((dw >> 24) << o3);   /* o3 <= 24: fits */
-    };
-    uint32_t bl, bh;
-    const uint32_t cl = chunk(lo, prev, nl, bl), ch = chunk(hi, lo >> 24, nh, bh);
-    const uint32_t tot = bl + bh;
+    const uint32_t tot = 8u * (uint32_t)nv - (uint32_t)__builtin_popcount(fl) - (uint32_t)__builtin_popcount(fh);
+    while (__ballot(fh != 0) != 0) {                     /* flags in bytes 4..7, the highest first */
+        if (fh) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(fh), bit = 1u << k, m = bit - 1u;
+            uint32_t nh = (hi & m) | ((hi >> 1) & ~m);
+            if (OR_SEM) nh |= hi & bit;
+            hi = nh;
+            fh &= m;
+        }
+    }
+    while (__ballot(fl != 0) != 0) {                     /* ... then bytes 0..3: the upper word moves down with them */
+        if (fl) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(fl), bit = 1u << k, m = bit - 1u;
+            uint32_t nl = (lo & m) | (__builtin_amdgcn_alignbit(hi, lo, 1) & ~m);
+            if (OR_SEM) nl |= lo & bit;
+            lo = nl;
+            hi >>= 1;
+            fl &= m;
+        }
+    }
     const uint32_t incl = wave_incl_scan_u32(tot, lane);
     const uint32_t off = base + incl - tot;
     if (nv > 0) {
-        const uint64_t c64 = (uint64_t)cl | ((uint64_t)ch << bl);       /* bl <= 32; bl == 32 only with four 8-bit bytes */
         const uint32_t sh = off & 31;
-        const uint64_t t = (uint64_t)(uint32_t)c64 << sh, u = (uint64_t)(uint32_t)(c64 >> 32) << sh;
-        atomicOr(&ms[off >> 5], (uint32_t)t);
-        atomicOr(&ms[(off >> 5) + 1], (uint32_t)(t >> 32) | (uint32_t)u);
-        if (sh + tot > 64) atomicOr(&ms[(off >> 5) + 2], (uint32_t)(u >> 32));
+        const uint64_t t = (uint64_t)lo << sh, u = (uint64_t)hi << sh;
+        uint32_t *o = out + (off >> 5);
+        atomicOr(o, (uint32_t)t);
+        atomicOr(o + 1, (uint32_t)(t >> 32) | (uint32_t)u);
+        if (sh + tot + (OR_SEM ? 1u : 0u) > 64) atomicOr(o + 2, (uint32_t)(u >> 32));   /* OR_SEM: bit `tot` may be set */
     }
     base += wave_last(incl);
+}
+
+/* forward streams: `dq` = the lane's eight bytes (dwords 2 (p0 + lane), 2 (p0 + lane) + 1 of the stream), `nbytes` the
+ * stream's length, `carry` the last byte of the pass before (0 at the start).  A byte that follows an 0xFF is flagged: one
+ * SWAR test per dword on the dword shifted up by a byte with the byte before it in front (x == 0xFF exactly when bit 7
+ * is set and the low seven bits carry into it when 1 is added). */
+template <bool OR_SEM>
+__device__ __forceinline__ void ht_unstuff_fwd_step8(uint2 dq, uint32_t p0, uint32_t nbytes, uint32_t *out, int lane,
+                                                     uint32_t &base, uint32_t &carry)
+{
+    uint32_t lo = dq.x, hi = dq.y;
+    int nv = 8;
+    if ((p0 + 64) * 8 > nbytes) {                        /* wave-uniform: the pass that holds the end of the stream */
+        nv = min(max((int)nbytes - (int)((p0 + lane) * 8), 0), 8);
+        const int nl = min(nv, 4), nh = nv - nl;
+        lo = nl == 4 ? lo : (nl ? lo & (0xFFFFFFFFu >> (32 - 8 * nl)) : 0u);
+        hi = nh == 4 ? hi : (nh ? hi & (0xFFFFFFFFu >> (32 - 8 * nh)) : 0u);
+    }
+    uint32_t prev = ht_dpp_left(hi >> 24);
+    if (lane == 0) prev = carry;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)(hi >> 24), 63);   /* the last byte of this pass */
+    const uint32_t Pl = (lo << 8) | prev, Ph = __builtin_amdgcn_alignbyte(hi, lo, 3);   /* the bytes in front of b0..b3, b4..b7 */
+    uint32_t fl = ((Pl & 0x7F7F7F7Fu) + 0x01010101u) & Pl & 0x80808080u;
+    uint32_t fh = ((Ph & 0x7F7F7F7Fu) + 0x01010101u) & Ph & 0x80808080u;
+    if (nv < 8) {                                        /* bytes past the stream carry no flag */
+        const int nl = min(nv, 4), nh = nv - nl;
+        fl = nl == 4 ? fl : (nl ? fl & (0xFFFFFFFFu >> (32 - 8 * nl)) : 0u);
+        fh = nh == 4 ? fh : (nh ? fh & (0xFFFFFFFFu >> (32 - 8 * nh)) : 0u);
+    }
+    ht_squeeze_place<OR_SEM>(lo, hi, fl, fh, nv, out, lane, base);
+}
+
+/* MagSgn bytes -> bit array (the name the kernels use) */
+__device__ __forceinline__ void ht_unstuff_magsgn_step8(uint2 dq, uint32_t p0, uint32_t Pcup, uint32_t *ms, int lane,
+                                                        uint32_t &base, uint32_t &carry)
+{
+    ht_unstuff_fwd_step8<true>(dq, p0, Pcup, ms, lane, base, carry);
 }
 
 __device__ __forceinline__ uint32_t ht_unstuff_magsgn(const uint8_t *__restrict__ D, uint32_t Pcup, uint32_t *ms, int lane)
@@ -493,6 +530,31 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const uint32_t *Dw_h[2] = { nullptr, nullptr };
     uint2 pv[2][4];                                          /* the first 2 KB of each block's MagSgn bytes */
 
+    /* ---- this lane's quad symbols of the first 32 quad rows, requested before anything else and kept in 16 registers
+     * (rows 2 k | 2 k + 1 << 16).  With one 2-byte load per row inside the row loop, the wait for row r + 1's symbol is
+     * -- the memory counter being in order -- also a wait for the row stores issued before that load: every row paid a
+     * store round trip (0.35 of the kernel's 1.24 ms).  Now the loop of a block of up to 64 rows holds no load at all and
+     * never waits for its stores.  Rows past the block's last are read from whatever follows in the symbol array
+     * (padded by the host) and are masked off below; lanes past the block's width read column 0. ---- */
+    const int bi = min(2 * (int)blockIdx.x + hf, nblocks - 1);
+    uint32_t sy[16];
+    {
+        const uint32_t wh = *(const uint32_t *)&blocks[bi].w;      /* w | h << 16 */
+        const int w_l = (int)(wh & 0xFFFFu), qw_l = (w_l + 1) >> 1;
+        const uint32_t qwp_l = ht_qsym_pitch((uint32_t)w_l);
+        const ht_sym_t *qp0 = qsym + qoff[bi] + (q < qw_l ? q : 0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t a = qp0[0], c = qp0[qwp_l];
+            sy[k] = a | (c << 16);
+            qp0 += 2 * qwp_l;
+        }
+        if (q >= qw_l) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) sy[k] = 0;
+        }
+    }
+
     /* ---- per block, whole wave: checks, zero-fill of blocks without passes; the MagSgn bytes of both blocks are
      * requested before either is worked on (a wave's start is a chain of dependent loads otherwise) ---- */
 #pragma unroll
@@ -562,7 +624,6 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     if (!ok_h[0] && !ok_h[1]) return;
 
     /* ---- both blocks in lockstep: this lane's block ---- */
-    const int bi = min(2 * (int)blockIdx.x + hf, nblocks - 1);
     const J2kBlock b = blocks[bi];
     const bool ok = hf ? ok_h[1] : ok_h[0];
     const int w = b.w, h = b.h, stride = b.stride, M_b = b.M_b;
@@ -590,33 +651,53 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
     const bool fast_blk = !ok || (pLSB >= dshift && pLSB >= 1 && pLSB <= 30 && maxbp <= 16);
     if (__ballot(!fast_blk) == 0) {
         const uint32_t up = (uint32_t)(pLSB - dshift) & 31u, hb = (halfbit & 0x7FFFFFFFu) >> (dshift & 31);
-        const uint32_t up2 = (up & 15u) * 0x00010001u, hb2 = (hb & 0xFFFFu) * 0x00010001u;
         /* SIMPLE (wave-uniform): both blocks have the same, even, height -- nearly every wave, the block table is sorted
          * by size.  Then which lanes store is fixed for the whole loop: lanes outside their block aim at the scratch
          * line from the start (stride 0), and every row issues exactly two stores behind the prefetch of the next row's
          * symbols, so that the wait at the loop top is vmcnt(2), not vmcnt(0) (see ht_magsgn_rows_narrow). */
-        auto fast_rows = [&](auto simple_tag) {
-        constexpr bool SIMPLE = decltype(simple_tag)::value;
+        /* Per-lane constants of the loop.  The exponent predictor only ever asks for the LARGEST exponent of four samples
+         * of the row above (this quad's two bottom samples, the left quad's bottom-right, the right quad's bottom-left,
+         * jpeg2000htdec.c:855-885), and max(32 - clz(a), 32 - clz(b)) = 32 - clz(a | b): so the row keeps the two bottom
+         * values themselves, packed (bottom-left | bottom-right << 16, each ORed with its significance bit so that a
+         * significant zero counts as exponent 1), the neighbours' halves are ORed in through two DPP moves, and ONE
+         * count-leading-zeros gives the maximum.  kappa = gamma ? max(E - 1, 1) : 1 = 1 + (gamma ? max(E - 2, 0) : 0).
+         * A quad outside the block reads symbol 0 and contributes nothing; nothing crosses the boundary between the two blocks (lanes 31 | 32). */
+        const uint32_t LmHi = q == 0 ? 0u : 0xFFFF0000u, RmLo = q == 31 ? 0u : 0x0000FFFFu;
+        /* dequantisation of two samples per instruction: ((v >> 1) + 1) << up | hb = (v >> 1) * 2^up + (2^up | hb), as hb < 2^up */
+        const uint32_t mul2 = ((1u << up) & 0xFFFFu) * 0x00010001u, add2 = (((1u << up) | hb) & 0xFFFFu) * 0x00010001u;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
+        /* PRE: the wave's blocks have at most 32 quad rows and their symbols sit in sy[] */
+        auto fast_rows = [&](auto simple_tag, auto pre_tag) {
+        constexpr bool SIMPLE = decltype(simple_tag)::value, PRE = decltype(pre_tag)::value;
         uint16_t *pt = (SIMPLE && !act) ? (uint16_t *)sink : prow;
         const int st = (SIMPLE && !act) ? 0 : stride;
+        uint32_t Zb = 0;                                                    /* the row above: bottom-left' | bottom-right' << 16 */
+        uint32_t sy2 = 0;
         for (int row = 0; row < rows; row++) {
             const bool arow = SIMPLE ? act : (act && row < qh);
-            const uint32_t qi = qi_next;
-            qp += qwp;
-            qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
-            /* field n of the symbol -> bits 0-1 of byte n; R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
-            const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);           /* (ORs, not one multiply: the shifted copies overlap) */
-            const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1, uq = qi >> 8;
-            const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
-            int kappa = 1;
-            if (row > 0) {
-                uint32_t l = ht_dpp_left(E3p), r = ht_dpp_right(E1p);
-                l = q == 0 ? 0u : l;
-                r = q == 31 ? 0u : r;
-                const int me = (int)max(max(E1p, E3p), max(l, r));
-                kappa = (R & (R - 1)) ? max(me - 1, 1) : 1;
+            uint32_t qi;
+            if (PRE) {
+                if (!(row & 1)) sy2 = sy[row >> 1];                         /* (uniform index) */
+                qi = (row & 1) ? sy2 >> 16 : sy2 & 0xFFFFu;
+                if (!SIMPLE) qi = arow ? qi : 0u;                           /* rows past this lane's block; a rejected block */
+            } else {
+                qi = qi_next;
+                qp += qwp;
+                qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
             }
-            const uint32_t U = (uint32_t)kappa + uq;
+            /* field n of the symbol -> bits 0-1 of byte n (ORs of shifted copies, not one multiply: the copies overlap and a
+             * product would carry); R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
+            const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);
+            const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1;
+            const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
+            /* kappa + u.  Row 0: Zb = 0, the maximum is "1", kappa = 1 */
+            uint32_t Z = (ht_dpp_left(Zb) & LmHi) | Zb;
+            Z = (ht_dpp_right(Zb) & RmLo) | Z;
+            const uint32_t Zf = ((Z >> 16) | Z | 1u) & 0xFFFFu;
+            const int em2 = max(30 - (int)__builtin_clz(Zf), 0);            /* max(E - 2, 0) */
+            const bool gamma = __builtin_amdgcn_sad_u8(R, 0u, 0u) > 1u;     /* more than one significant sample */
+            const uint32_t U = (gamma ? (uint32_t)em2 : 0u) + 1u + (qi >> 8);
             if (arow && (int)U > maxbp) err = 1;
             uint32_t Rs = R << 8;
             asm("" : "+v"(Rs));                                             /* (or the compiler makes it R * 255: v_mul_lo_u32 is quarter rate) */
@@ -630,32 +711,33 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             const uint32_t wi = min(pos >> 5, last_wi + 1);
             const uint32_t w0 = ms[wi], w1 = ms[wi + 1], w2 = ms[wi + 2];
             uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pos), hi = __builtin_amdgcn_alignbit(w2, w1, pos);
-            const uint32_t n0 = N & 0xFF, n1 = (N >> 8) & 0xFF, n2 = (N >> 16) & 0xFF, n3 = N >> 24;
-            uint32_t v0 = __builtin_amdgcn_ubfe(lo, 0u, n0);
-            lo = __builtin_amdgcn_alignbit(hi, lo, n0); hi >>= (n0 & 31);
-            uint32_t v1 = __builtin_amdgcn_ubfe(lo, 0u, n1);
-            lo = __builtin_amdgcn_alignbit(hi, lo, n1); hi >>= (n1 & 31);
-            uint32_t v2 = __builtin_amdgcn_ubfe(lo, 0u, n2);
-            lo = __builtin_amdgcn_alignbit(hi, lo, n2);
-            uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, n3);
-            v0 += (X1 & 1) << n0; v1 += ((X1 >> 8) & 1) << n1; v2 += ((X1 >> 16) & 1) << n2; v3 += (X1 >> 24) << n3;
-            /* bottom-left and bottom-right feed the next row */
-            E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)-(int)((R >> 8) & 1);
-            E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)-(int)(R >> 24);
+            /* the bit counts as shift amounts and field widths: the instructions look at the low five bits only (m_n <= 16 here) */
+            const uint32_t N1 = N >> 8, N2 = N >> 16, N3 = N >> 24;
+            const uint32_t v0 = __builtin_amdgcn_ubfe(lo, 0u, N);
+            lo = __builtin_amdgcn_alignbit(hi, lo, N); hi = __builtin_amdgcn_alignbit(0u, hi, N);
+            const uint32_t v1 = __builtin_amdgcn_ubfe(lo, 0u, N1);
+            lo = __builtin_amdgcn_alignbit(hi, lo, N1); hi = __builtin_amdgcn_alignbit(0u, hi, N1);
+            const uint32_t v2 = __builtin_amdgcn_ubfe(lo, 0u, N2);
+            lo = __builtin_amdgcn_alignbit(hi, lo, N2);
+            const uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, N3);
+            /* pairs: top = samples 0 | 2 << 16, bottom = 1 | 3 << 16; the known MSB goes in at bit m_n (where it is known the bound
+             * took a bit away, m_n <= 15: the 16-bit shift sees the low four bits of each half of N resp. N >> 8) */
+            uint32_t Pt = v0 | (v2 << 16), Pb = v1 | (v3 << 16), xt, xb;
+            asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(xt) : "v"(N), "v"(X1 & 0x00010001u));
+            asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(xb) : "v"(N1), "v"((X1 >> 8) & 0x00010001u));
+            Pt |= xt; Pb |= xb;
+            const uint32_t sgT = R & 0x00010001u, sgB = (R >> 8) & 0x00010001u;
+            Zb = Pb | sgB;                                                  /* feeds the next row */
             /* mu (:407-427) -> dequantization_int, two samples per instruction: v < 2^16 (at most 16 magnitude bits, the
              * known MSB only where the bound took one away), the result < 2^M_b <= 2^15 -- and whatever a block that is
-             * about to be rejected overflows stays inside its own half */
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            auto samples = [&](uint32_t va, uint32_t vb, uint32_t sig) -> uint32_t {   /* sig: bit 0 / 16 = sample a / b is significant */
-                const u16x2 one = { 1, 1 };
-                const u16x2 P = __builtin_bit_cast(u16x2, va | (vb << 16));
-                u16x2 r = ((P >> one) + one) << __builtin_bit_cast(u16x2, up2);
-                r |= __builtin_bit_cast(u16x2, hb2);
-                const u16x2 sg = (u16x2){ 0, 0 } - (P & one);
-                r = (r ^ sg) - sg;
-                return __builtin_bit_cast(uint32_t, r) & __builtin_bit_cast(uint32_t, (u16x2)((u16x2){ 0, 0 } - __builtin_bit_cast(u16x2, sig)));
+             * about to be rejected overflows stays inside its own half.  The sign (bit 0 of v) and "not significant" are
+             * one multiplier: +1, -1 or 0 */
+            auto samples = [&](uint32_t P, uint32_t sig) -> uint32_t {
+                const u16x2 r = (__builtin_bit_cast(u16x2, P) >> (u16x2){ 1, 1 }) * __builtin_bit_cast(u16x2, mul2) + __builtin_bit_cast(u16x2, add2);
+                const i16x2 m = __builtin_bit_cast(i16x2, P & 0x00010001u) * (i16x2){ -2, -2 } + __builtin_bit_cast(i16x2, sig);
+                return __builtin_bit_cast(uint32_t, (u16x2)(r * __builtin_bit_cast(u16x2, m)));
             };
-            const uint32_t top = samples(v0, v2, R & 0x00010001u), bot = samples(v1, v3, (R >> 8) & 0x00010001u);
+            const uint32_t top = samples(Pt, sgT), bot = samples(Pb, sgB);
             if (SIMPLE) {
                 *(uint32_t *)pt = top;
                 *(uint32_t *)(pt + st) = bot;
@@ -668,8 +750,12 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         }
         };
         const int qh0 = __builtin_amdgcn_readlane(qh, 0), qh1 = __builtin_amdgcn_readlane(qh, 32);
-        if (qh0 == qh1 && __ballot(ok && (h & 1)) == 0) fast_rows(std::true_type{});
-        else fast_rows(std::false_type{});
+        const bool simple = qh0 == qh1 && __ballot(ok && (h & 1)) == 0;
+        if (rows <= 32) {
+            if (simple) fast_rows(std::true_type{}, std::true_type{}); else fast_rows(std::false_type{}, std::true_type{});
+        } else {
+            if (simple) fast_rows(std::true_type{}, std::false_type{}); else fast_rows(std::false_type{}, std::false_type{});
+        }
     } else
     for (int row = 0; row < rows; row++) {
         const bool arow = act && row < qh;
@@ -1406,46 +1492,50 @@ k_ht_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__r
  * k_ht_decode<true> (wave per block)  MagSgn + dequantisation + refinement passes.
  * The host sorts the block table by size so that the 64 lanes of a k_ht_vlc wave run similar
  * trip counts. */
-/* Backward byte stream (VLC, MagRef): bytes top[0], top[-1], ... top[-(n-1)] in read order, four per lane and
+/* Backward byte stream (VLC, MagRef): bytes top[0], top[-1], ... top[-(n-1)] in read order, eight per lane and
  * pass.  A byte whose 7 LSBs are set loses its MSB when the byte read before it is > 0x8F
- * (jpeg2000htdec.c:145-201); the byte "before" the first one is 0xFF.  `first_or` is ORed into the first
- * byte (the VLC stream's Dcup[Lcup-2] counts with its low nibble set, :1277-1278).  `out` (LDS) is zeroed. */
-__device__ __forceinline__ void ht_unstuff_backward_step(uint32_t dw, uint32_t k0, uint32_t n, uint32_t first_or,
-                                                         uint32_t *out, int lane, uint32_t &base, uint32_t &carry)
+ * (jpeg2000htdec.c:145-201); the byte "before" the first one is 0xFF (carry starts as 0x80: "was > 0x8F").
+ * `first_or` is ORed into the first byte (the VLC stream's Dcup[Lcup-2] counts with its low nibble set,
+ * :1277-1278).  `dq` = the eight memory bytes top[-k-7 .. -k], k = k0 + 8 lane: byte-swapped they are the lane's
+ * bytes in read order.  `out` (LDS) is zeroed. */
+__device__ __forceinline__ void ht_unstuff_backward_step8(uint2 dq, uint32_t k0, uint32_t n, uint32_t first_or,
+                                                          uint32_t *out, int lane, uint32_t &base, uint32_t &carry)
 {
-    const uint32_t k = k0 + 4 * lane;                    /* read index of r0; dw = the four bytes top[-k-3 .. -k] */
-    const int nv = min(max((int)n - (int)k, 0), 4);
-    uint32_t r0 = dw >> 24, r1 = (dw >> 16) & 0xFF, r2 = (dw >> 8) & 0xFF, r3 = dw & 0xFF;
-    if (k == 0) r0 |= first_or;
-    if (nv < 4) { r3 = 0; if (nv < 3) r2 = 0; if (nv < 2) r1 = 0; if (nv < 1) r0 = 0; }
-    uint32_t above = ht_dpp_left(r3);
-    if (lane == 0) above = carry;
-    carry = (uint32_t)__builtin_amdgcn_readlane((int)r3, 63);
-    const uint32_t n0 = nv > 0 ? ((above > 0x8F && (r0 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-    const uint32_t n1 = nv > 1 ? ((r0 > 0x8F && (r1 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-    const uint32_t n2 = nv > 2 ? ((r1 > 0x8F && (r2 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-    const uint32_t n3 = nv > 3 ? ((r2 > 0x8F && (r3 & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-    const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
-    const uint32_t chunk = (r0 & ((1u << n0) - 1)) | ((r1 & ((1u << n1) - 1)) << o1) |
-                           ((r2 & ((1u << n2) - 1)) << o2) | ((r3 & ((1u << n3) - 1)) << o3);
-    const uint32_t incl = wave_incl_scan_u32(tot, lane);
-    const uint32_t off = base + incl - tot, sh = off & 31;
-    if (nv > 0) {
-        atomicOr(&out[off >> 5], chunk << sh);
-        if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
+    const uint32_t k = k0 + 8 * lane;
+    uint32_t lo = __builtin_bswap32(dq.y), hi = __builtin_bswap32(dq.x);
+    if (k == 0) lo |= first_or;
+    int nv = 8;
+    if (k0 + 512 > n) {                                  /* wave-uniform: the pass that holds the end of the stream */
+        nv = min(max((int)n - (int)k, 0), 8);
+        const int nl = min(nv, 4), nh = nv - nl;
+        lo = nl == 4 ? lo : (nl ? lo & (0xFFFFFFFFu >> (32 - 8 * nl)) : 0u);
+        hi = nh == 4 ? hi : (nh ? hi & (0xFFFFFFFFu >> (32 - 8 * nh)) : 0u);
     }
-    base += wave_last(incl);
+    /* A: byte > 0x8F (top bit set and the low seven >= 0x10); B: low seven bits all set -- flags at bit 7 of each byte */
+    const uint32_t ll = lo & 0x7F7F7F7Fu, lh = hi & 0x7F7F7F7Fu;
+    const uint32_t Al = (ll + 0x70707070u) & lo & 0x80808080u, Ah = (lh + 0x70707070u) & hi & 0x80808080u;
+    const uint32_t Bl = (ll + 0x01010101u) & 0x80808080u, Bh = (lh + 0x01010101u) & 0x80808080u;
+    uint32_t prevA = ht_dpp_left(Ah >> 24);              /* the flag of the byte read just before this lane's first */
+    if (lane == 0) prevA = carry;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)(Ah >> 24), 63);
+    uint32_t fl = Bl & ((Al << 8) | prevA), fh = Bh & __builtin_amdgcn_alignbyte(Ah, Al, 3);
+    if (nv < 8) {                                        /* bytes past the stream are zero: B is clear there already */
+        const int nl = min(nv, 4), nh = nv - nl;
+        fl = nl == 4 ? fl : (nl ? fl & (0xFFFFFFFFu >> (32 - 8 * nl)) : 0u);
+        fh = nh == 4 ? fh : (nh ? fh & (0xFFFFFFFFu >> (32 - 8 * nh)) : 0u);
+    }
+    ht_squeeze_place<false>(lo, hi, fl, fh, nv, out, lane, base);
 }
 
 __device__ __forceinline__ uint32_t ht_unstuff_backward(const uint8_t *__restrict__ top, uint32_t n, uint32_t first_or,
                                                         uint32_t *out, int lane)
 {
-    uint32_t base = 0, carry = 0xFF;
-    for (uint32_t k0 = 0; k0 < n; k0 += 256) {
-        const uint32_t k = k0 + 4 * lane;
-        uint32_t dw = 0;
-        if (k < n) __builtin_memcpy(&dw, top - k - 3, 4);      /* up to 3 bytes in front of the stream: block bytes or pad */
-        ht_unstuff_backward_step(dw, k0, n, first_or, out, lane, base, carry);
+    uint32_t base = 0, carry = 0x80;
+    for (uint32_t k0 = 0; k0 < n; k0 += 512) {
+        const uint32_t k = k0 + 8 * lane;
+        uint2 dq = make_uint2(0u, 0u);
+        if (k < n) __builtin_memcpy(&dq, top - k - 7, 8);      /* up to 7 bytes in front of the stream: block bytes or pad */
+        ht_unstuff_backward_step8(dq, k0, n, first_or, out, lane, base, carry);
     }
     return base;
 }
@@ -1455,30 +1545,11 @@ __device__ __forceinline__ uint32_t ht_unstuff_backward(const uint8_t *__restric
 __device__ __forceinline__ uint32_t ht_unstuff_forward7(const uint8_t *__restrict__ src, uint32_t n, uint32_t *out, int lane)
 {
     uint32_t base = 0, carry = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-        const uint32_t i = i0 + 4 * lane;
-        const int nv = min(max((int)n - (int)i, 0), 4);
-        uint32_t dw = 0;
-        if (nv > 0) __builtin_memcpy(&dw, src + i, 4);
-        if (nv < 4) dw &= nv ? (0xFFFFFFFFu >> (32 - 8 * nv)) : 0u;
-        const uint32_t b0 = dw & 0xFF, b1 = (dw >> 8) & 0xFF, b2 = (dw >> 16) & 0xFF, b3 = dw >> 24;
-        uint32_t prev = ht_dpp_left(b3);
-        if (lane == 0) prev = carry;
-        carry = (uint32_t)__builtin_amdgcn_readlane((int)b3, 63);
-        const uint32_t n0 = nv > 0 ? (prev == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n1 = nv > 1 ? (b0 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n2 = nv > 2 ? (b1 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t n3 = nv > 3 ? (b2 == 0xFF ? 7u : 8u) : 0u;
-        const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, tot = o3 + n3;
-        const uint32_t chunk = (b0 & ((1u << n0) - 1)) | ((b1 & ((1u << n1) - 1)) << o1) |
-                               ((b2 & ((1u << n2) - 1)) << o2) | ((b3 & ((1u << n3) - 1)) << o3);
-        const uint32_t incl = wave_incl_scan_u32(tot, lane);
-        const uint32_t off = base + incl - tot, sh = off & 31;
-        if (nv > 0) {
-            atomicOr(&out[off >> 5], chunk << sh);
-            if (sh) atomicOr(&out[(off >> 5) + 1], chunk >> (32 - sh));
-        }
-        base += wave_last(incl);
+    for (uint32_t p0 = 0; p0 * 8 < n; p0 += 64) {
+        const uint32_t i = (p0 + lane) * 8;
+        uint2 dq = make_uint2(0u, 0u);
+        if (i < n) __builtin_memcpy(&dq, src + i, 8);           /* up to 7 bytes behind the stream: block bytes or pad */
+        ht_unstuff_fwd_step8<false>(dq, p0, n, out, lane, base, carry);
     }
     return base;
 }
@@ -1502,12 +1573,12 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     /* A wave lives as long as its chain of dependent global loads.  The first 1024 bytes of the VLC stream (read
      * backward from Dcup[Lcup-2]) are fetched before Scup -- which says how many of them count -- is known: the
      * addresses depend on Lcup only and stay inside the byte pool (blocks in front, 16 bytes of pad at its start). */
-    uint32_t pv[4];
+    uint2 pv[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const long long o = (long long)b.data_off + Lcup - 5 - (256 * j + 4 * lane);
-        pv[j] = 0;
-        if (o >= 0) __builtin_memcpy(&pv[j], bytes + o, 4);
+    for (int j = 0; j < 2; j++) {
+        const long long o = (long long)b.data_off + Lcup - 9 - (512 * j + 8 * lane);
+        pv[j] = make_uint2(0u, 0u);
+        if (o >= 0) __builtin_memcpy(&pv[j], bytes + o, 8);
     }
     const uint32_t Scup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F)));
     if (Scup < 2 || Scup > Lcup || Scup > 4079) return;
@@ -1523,15 +1594,15 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
     {
         const uint8_t *top = D + Lcup - 2;
         const uint32_t n = Scup - 1;
-        uint32_t base = 0, carry = 0xFF;
+        uint32_t base = 0, carry = 0x80;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (256u * j < n) ht_unstuff_backward_step(pv[j], 256 * j, n, 0x0F, sv, lane, base, carry);
-        for (uint32_t k0 = 1024; k0 < n; k0 += 256) {
-            const uint32_t k = k0 + 4 * lane;
-            uint32_t dw = 0;
-            if (k < n) __builtin_memcpy(&dw, top - k - 3, 4);
-            ht_unstuff_backward_step(dw, k0, n, 0x0F, sv, lane, base, carry);
+        for (int j = 0; j < 2; j++)
+            if (512u * j < n) ht_unstuff_backward_step8(pv[j], 512 * j, n, 0x0F, sv, lane, base, carry);
+        for (uint32_t k0 = 1024; k0 < n; k0 += 512) {
+            const uint32_t k = k0 + 8 * lane;
+            uint2 dq = make_uint2(0u, 0u);
+            if (k < n) __builtin_memcpy(&dq, top - k - 7, 8);
+            ht_unstuff_backward_step8(dq, k0, n, 0x0F, sv, lane, base, carry);
         }
     }
 

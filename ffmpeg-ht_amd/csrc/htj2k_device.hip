@@ -1032,7 +1032,8 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
     if ((r = j->d_coef.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t0.ensure(coef_bytes)) < 0) return r;
     if ((r = j->d_t1.ensure(coef_bytes)) < 0) return r;
-    if ((r = j->d_qsym.ensure(j->nquads * sizeof(ht_sym_t) + 256)) < 0) return r;      /* + the scratch line of k_ht_vlc's flush */
+    /* + the scratch line of k_ht_vlc's flush, + what k_ht_decode_pair's symbol preload reads past the last block (32 rows of 34) */
+    if ((r = j->d_qsym.ensure(j->nquads * sizeof(ht_sym_t) + 256 + 8192)) < 0) return r;
     if ((r = j->d_qoff.ensure((j->qoff.size() + 1) * sizeof(uint32_t))) < 0) return r;
     /* a corrupt block can run k_ht_vlc's bit positions past its own arrays (38 VLC / 18 MEL bits per quad pair at
      * most, 4096 samples per block: < 3 KB): the last block of the pool must still read inside the allocation */
