@@ -106,6 +106,21 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+/* the MagSgn bit array of a block in LDS: `p` is 16-byte aligned and its region a multiple of 16 bytes (the host rounds
+ * ms_words up), so the clearing runs 16 bytes per lane; past the end of the stream the array is all ones
+ * (jpeg2000htdec.c:207-221) -- only the words from the one that holds bit `total` on need touching */
+__device__ __forceinline__ void ht_ms_clear(uint32_t *p, uint32_t nwords, int lane)
+{
+    for (uint32_t i = 4u * lane; i < nwords; i += 256) *(uint4 *)(p + i) = make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void ht_ms_ones_tail(uint32_t *p, uint32_t total, uint32_t last_word, int lane)
+{
+    for (uint32_t i = (total >> 5) + lane; i <= last_word; i += 64) {
+        if (i * 32 >= total) p[i] = 0xFFFFFFFFu;
+        else p[i] |= 0xFFFFFFFFu << (total & 31);
+    }
+}
+
 /* dequantise one sign-magnitude sample (bit 31 sign, magnitude LSB at 31 - M_b) */
 __device__ __forceinline__ uint32_t ht_dequant(uint32_t smag, int transform, int M_b, int roi_shift,
                                                float fscale, int i_step)
@@ -603,7 +618,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         const uint32_t Pcup = Pcup_h[hb];
         uint32_t *ms = ms_all + hb * mspitch;
         const uint32_t nms = (Pcup * 8 + 31) / 32 + 2;
-        for (uint32_t i = lane; i <= nms + 1; i += 64) ms[i] = 0;
+        ht_ms_clear(ms, nms + 2, lane);
         __syncthreads();
         uint32_t ms_total = 0, carry = 0;
 #pragma unroll
@@ -614,10 +629,7 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             ht_unstuff_magsgn_step8(pi * 8 < Pcup ? ((const uint2 *)Dw_h[hb])[pi] : make_uint2(0u, 0u), p0, Pcup, ms, lane, ms_total, carry);
         }
         __syncthreads();
-        for (uint32_t i = lane; i <= nms + 1; i += 64) {     /* past the end the MagSgn stream is all ones (:207-221) */
-            if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
-            else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
-        }
+        ht_ms_ones_tail(ms, ms_total, nms + 1, lane);        /* past the end the MagSgn stream is all ones (:207-221) */
         lastwi_h[hb] = nms - 2;                              /* words last_wi .. last_wi + 3 exist and are ones past the end */
     }
     __syncthreads();
@@ -666,29 +678,22 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
         /* dequantisation of two samples per instruction: ((v >> 1) + 1) << up | hb = (v >> 1) * 2^up + (2^up | hb), as hb < 2^up */
         const uint32_t mul2 = ((1u << up) & 0xFFFFu) * 0x00010001u, add2 = (((1u << up) | hb) & 0xFFFFu) * 0x00010001u;
         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        typedef short i16x2 __attribute__((ext_vector_type(2)));
         /* PRE: the wave's blocks have at most 32 quad rows and their symbols sit in sy[] */
         auto fast_rows = [&](auto simple_tag, auto pre_tag) {
         constexpr bool SIMPLE = decltype(simple_tag)::value, PRE = decltype(pre_tag)::value;
         uint16_t *pt = (SIMPLE && !act) ? (uint16_t *)sink : prow;
         const int st = (SIMPLE && !act) ? 0 : stride;
         uint32_t Zb = 0;                                                    /* the row above: bottom-left' | bottom-right' << 16 */
-        uint32_t sy2 = 0;
-        for (int row = 0; row < rows; row++) {
+        uint32_t Umax = 0;                                                  /* SIMPLE: the error test (U > maxbp) once, after the loop */
+        const uint32_t minus2 = 0xFFFEFFFEu;
+        /* one quad row; `sym` holds the lane's symbol in its low (HI = false) or high 16 bits */
+        auto quad_row = [&](int row, uint32_t sym, auto hi_tag) {
+            constexpr bool HI = decltype(hi_tag)::value;
             const bool arow = SIMPLE ? act : (act && row < qh);
-            uint32_t qi;
-            if (PRE) {
-                if (!(row & 1)) sy2 = sy[row >> 1];                         /* (uniform index) */
-                qi = (row & 1) ? sy2 >> 16 : sy2 & 0xFFFFu;
-                if (!SIMPLE) qi = arow ? qi : 0u;                           /* rows past this lane's block; a rejected block */
-            } else {
-                qi = qi_next;
-                qp += qwp;
-                qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
-            }
             /* field n of the symbol -> bits 0-1 of byte n (ORs of shifted copies, not one multiply: the copies overlap and a
              * product would carry); R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
-            const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);
+            const uint32_t pk = HI ? (sym >> 16) & 0xFFu : sym & 0xFFu, uq = HI ? sym >> 24 : (sym >> 8) & 0xFFu;
+            const uint32_t pk2 = pk | (pk << 12);
             const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1;
             const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
             /* kappa + u.  Row 0: Zb = 0, the maximum is "1", kappa = 1 */
@@ -697,8 +702,9 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             const uint32_t Zf = ((Z >> 16) | Z | 1u) & 0xFFFFu;
             const int em2 = max(30 - (int)__builtin_clz(Zf), 0);            /* max(E - 2, 0) */
             const bool gamma = __builtin_amdgcn_sad_u8(R, 0u, 0u) > 1u;     /* more than one significant sample */
-            const uint32_t U = (gamma ? (uint32_t)em2 : 0u) + 1u + (qi >> 8);
-            if (arow && (int)U > maxbp) err = 1;
+            const uint32_t U = (gamma ? (uint32_t)em2 : 0u) + 1u + uq;
+            if (SIMPLE) Umax = max(Umax, U);                                /* (lanes outside their block: symbol 0, U = 1) */
+            else if (arow && (int)U > maxbp) err = 1;
             uint32_t Rs = R << 8;
             asm("" : "+v"(Rs));                                             /* (or the compiler makes it R * 255: v_mul_lo_u32 is quarter rate) */
             const uint32_t Rm = Rs - R;                                     /* 0xFF in the bytes of significant samples */
@@ -720,21 +726,25 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
             const uint32_t v2 = __builtin_amdgcn_ubfe(lo, 0u, N2);
             lo = __builtin_amdgcn_alignbit(hi, lo, N2);
             const uint32_t v3 = __builtin_amdgcn_ubfe(lo, 0u, N3);
-            /* pairs: top = samples 0 | 2 << 16, bottom = 1 | 3 << 16; the known MSB goes in at bit m_n (where it is known the bound
-             * took a bit away, m_n <= 15: the 16-bit shift sees the low four bits of each half of N resp. N >> 8) */
-            uint32_t Pt = v0 | (v2 << 16), Pb = v1 | (v3 << 16), xt, xb;
+            /* pairs: top = samples 0 | 2 << 16, bottom = 1 | 3 << 16 (one byte permute each: v < 2^16); the known MSB goes in at
+             * bit m_n (where it is known the bound took a bit away, m_n <= 15: the 16-bit shift sees the low four bits of each
+             * half of N resp. N >> 8).  The bottom pair's masks are the 16-bit halves of R and X1 shifted down a byte. */
+            uint32_t xt, xb, sgB, X1b;
+            asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(sgB) : "v"(R));   /* (the constant's low half for both lanes) */
+            asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(X1b) : "v"(X1));
             asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(xt) : "v"(N), "v"(X1 & 0x00010001u));
-            asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(xb) : "v"(N1), "v"((X1 >> 8) & 0x00010001u));
-            Pt |= xt; Pb |= xb;
-            const uint32_t sgT = R & 0x00010001u, sgB = (R >> 8) & 0x00010001u;
+            asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(xb) : "v"(N1), "v"(X1b));
+            const uint32_t Pt = __builtin_amdgcn_perm(v2, v0, 0x05040100u) | xt, Pb = __builtin_amdgcn_perm(v3, v1, 0x05040100u) | xb;
+            const uint32_t sgT = R & 0x00010001u;
             Zb = Pb | sgB;                                                  /* feeds the next row */
             /* mu (:407-427) -> dequantization_int, two samples per instruction: v < 2^16 (at most 16 magnitude bits, the
              * known MSB only where the bound took one away), the result < 2^M_b <= 2^15 -- and whatever a block that is
              * about to be rejected overflows stays inside its own half.  The sign (bit 0 of v) and "not significant" are
-             * one multiplier: +1, -1 or 0 */
+             * one multiplier: sig - 2 (v & 1) = +1, -1 or 0 */
             auto samples = [&](uint32_t P, uint32_t sig) -> uint32_t {
                 const u16x2 r = (__builtin_bit_cast(u16x2, P) >> (u16x2){ 1, 1 }) * __builtin_bit_cast(u16x2, mul2) + __builtin_bit_cast(u16x2, add2);
-                const i16x2 m = __builtin_bit_cast(i16x2, P & 0x00010001u) * (i16x2){ -2, -2 } + __builtin_bit_cast(i16x2, sig);
+                uint32_t m;
+                asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(m) : "v"(P & 0x00010001u), "v"(minus2), "v"(sig));
                 return __builtin_bit_cast(uint32_t, (u16x2)(r * __builtin_bit_cast(u16x2, m)));
             };
             const uint32_t top = samples(Pt, sgT), bot = samples(Pb, sgB);
@@ -747,7 +757,26 @@ k_ht_decode_pair(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t
                 *((arow && two) ? (uint32_t *)(pt + st) : sink) = bot;
             }
             pt += 2 * st;
+        };
+        if (PRE) {                                                          /* two rows per register, no load in the loop */
+            for (int k = 0; 2 * k < rows; k++) {
+                uint32_t s2 = sy[k];                                        /* (uniform index) */
+                if (!SIMPLE) {                                              /* rows past this lane's block; a rejected block */
+                    s2 = (act && 2 * k < qh) ? s2 : 0u;
+                    s2 = (2 * k + 1 < qh) ? s2 : s2 & 0xFFFFu;
+                }
+                quad_row(2 * k, s2, std::false_type{});
+                if (2 * k + 1 < rows) quad_row(2 * k + 1, s2, std::true_type{});
+            }
+        } else {
+            for (int row = 0; row < rows; row++) {
+                const uint32_t qi = qi_next;
+                qp += qwp;
+                qi_next = (act && row + 1 < (SIMPLE ? rows : qh)) ? *qp : 0u;
+                quad_row(row, qi, std::false_type{});
+            }
         }
+        if (SIMPLE && act && (int)Umax > maxbp) err = 1;
         };
         const int qh0 = __builtin_amdgcn_readlane(qh, 0), qh1 = __builtin_amdgcn_readlane(qh, 32);
         const bool simple = qh0 == qh1 && __ballot(ok && (h & 1)) == 0;
@@ -917,7 +946,7 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         const uint32_t Pcup = Pcup_s[hb];
         uint32_t *ms = ms_all + hb * mspitch;
         const uint32_t nms = (Pcup * 8 + 31) / 32 + 2;
-        for (uint32_t i = lane; i <= nms + 1; i += 64) ms[i] = 0;
+        ht_ms_clear(ms, nms + 2, lane);
         __syncthreads();
         uint32_t ms_total = 0, carry = 0;
 #pragma unroll
@@ -928,10 +957,7 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
             ht_unstuff_magsgn_step8(pi * 8 < Pcup ? ((const uint2 *)Dw_s[hb])[pi] : make_uint2(0u, 0u), p0, Pcup, ms, lane, ms_total, carry);
         }
         __syncthreads();
-        for (uint32_t i = lane; i <= nms + 1; i += 64) {     /* past the end the MagSgn stream is all ones (:207-221) */
-            if (i * 32 >= ms_total) ms[i] = 0xFFFFFFFFu;
-            else if (i * 32 + 32 > ms_total) ms[i] |= 0xFFFFFFFFu << (ms_total & 31);
-        }
+        ht_ms_ones_tail(ms, ms_total, nms + 1, lane);        /* past the end the MagSgn stream is all ones (:207-221) */
         lastwi_s[hb] = nms - 2;                              /* words last_wi .. last_wi + 3 exist and are ones past the end */
     }
     __syncthreads();
@@ -2002,11 +2028,16 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
      * a context looks at, jpeg2000htdec.c:725-760), shifted along with the walk: bit j of A1 / A3 = quad qx + j, L1 / L3
      * = quad qx - 1; bit q of N1 / N3 collects the current row */
     uint32_t A1 = 0, A3 = 0, L1 = 0, L3 = 0, N1 = 0, N3 = 0;
-    for (int t = 0; t < max_it; t++) {
-        const bool active = t < n_it;
-        const uint16_t *table = tbl + (row ? 1024 : 0);
-        const bool row0 = row == 0;
-        const bool pair = qx + 1 < qw;
+    /* One pass of the loop.  MAIN: every lane of the wave is inside its block and past the first quad row, and every block
+     * has an even number of quads per row -- all but the first and the last few passes of nearly every wave (the block
+     * table is sorted by size).  Then nothing is predicated: both quads of the pair exist, the contexts come from the row
+     * above, the first-row U-VLC rule (:666-712) cannot apply.  The general form runs the ragged start and end. */
+    auto pass = [&](int t, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value && NARROW;
+        const bool active = MAIN || t < n_it;
+        const uint16_t *table = tbl + ((MAIN || row) ? 1024 : 0);
+        const bool row0 = !MAIN && row == 0;
+        const bool pair = MAIN || qx + 1 < qw;
         if ((t & 1) == 0) {
             if (pend) {
                 uint32_t *r = vst + (pw & 15);
@@ -2136,7 +2167,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 ral = ra;
                 ra_next = rar;
                 if (NARROW) { N1 |= (((uint32_t)rho[k] >> 1) & 1u) << q; N3 |= (((uint32_t)rho[k] >> 3) & 1u) << q; }
-                ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);
+                if (!MAIN) ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);   /* first row only */
             }
         }
         /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) for both quads, branch-free, on a
@@ -2182,7 +2213,20 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             if (NARROW) { A1 = N1; A3 = N3; L1 = 0; L3 = 0; N1 = 0; N3 = 0; }
             else ra_next = (int)myrho[0];                /* above quad 0 of the new row */
         }
+    };
+    /* [0, t_a): some lane is still in its first row; [t_a, t_b): the MAIN form; [t_b, max_it): some lane is done */
+    int t_a = ppr, t_b = n_it, odd = qw & 1;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        t_a = max(t_a, __shfl_xor(t_a, o));
+        t_b = min(t_b, __shfl_xor(t_b, o));
+        odd |= __shfl_xor(odd, o);
     }
+    if (!NARROW || odd || t_b < t_a) t_a = t_b = max_it;   /* no MAIN stretch */
+    int t = 0;
+    for (; t < t_a; t++) pass(t, std::false_type{});
+    for (; t < t_b; t++) pass(t, std::true_type{});
+    for (; t < max_it; t++) pass(t, std::false_type{});
     if (max_it > 0) flush((max_it - 1) / CAD);
 }
 

@@ -652,7 +652,7 @@ static int ht_lds_layout(htj2k_ctx *c, uint32_t max_p, uint32_t max_s, uint32_t 
 {
     HtLds &L = *out;
     size_t off = 4096;                                   /* the two CxtVLC tables */
-    L.ms_words = (max_p * 8 + 31) / 32 + 3;
+    L.ms_words = ((max_p * 8 + 31) / 32 + 3 + 3) & ~3u;  /* a multiple of 4: the kernels clear the array 16 bytes per lane */
     L.off_ms = (uint32_t)off;  off += (size_t)L.ms_words * 4;
     L.vlc_words = (max_s * 8 + 31) / 32 + 2;
     L.off_vlc = (uint32_t)off; off += (size_t)L.vlc_words * 4;
