@@ -2230,4 +2230,352 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     if (max_it > 0) flush((max_it - 1) / CAD);
 }
 
+
+/* ================================================================== k_ht_vlc2
+ * k_ht_vlc for launches without a block wider than 64 columns (nearly every stream), with everything a pass computes
+ * rearranged around what costs instructions -- the kernel is bound by VALU issue (SQ counters: profiles/r03_ht_sq.csv):
+ *   contexts   A context of a quad below the first row looks at three things (jpeg2000htdec.c:725-760): c0 = the
+ *              sample above-left or above, c2 = above-right, and the quad to the left.  c0 and c2 of ALL quads of a row
+ *              are made at once when the row above ends: that row's (rho bit 1, rho bit 3) pairs were shifted into a
+ *              64-bit register M as they were decoded, and with I = M in quad order
+ *                  D = ((I | I << 1) & 0x55...) | ((I | I >> 1) & 0xAA...)
+ *              holds (c0, c2) of quad q at bits 2 q, 2 q + 1.  A pass takes its four bits off the bottom of D.
+ *   tables     The CxtVLC table of the other rows is stored under the index  codeword bits | c0 << 7 | c2 << 8 | left << 9,
+ *              so the byte address is  bits << 1 | (D & 3) << 8 | left << 10  and "context 0" is "address < 0x100".  An
+ *              entry is  u_off | len << 1 | rho bit 1 << 4 | rho bit 3 << 5 | (rho bit 2 or 3) << 6 | fields << 8:
+ *              what the NEXT quads ask of this one is in the entry, rho itself is not (the first row, which needs all of
+ *              it for its running context, gets it back from the fields).
+ *   MEL        A quad in context 0 whose MEL symbol is 0 decodes nothing: the entry is multiplied by (symbol | not context 0).
+ *   U-VLC      32-bit entries laid out so that they serve as operands as they are: prefix length in bits 0-4 (the offset of
+ *              the first suffix), the offset of the second suffix in bits 11-15, both prefixes at the byte positions of
+ *              the two u of the output word; suffix extensions (u > 32) in a branch that is taken when a lane has one.
+ *   stream     a ring of 16 words per lane with its first two words mirrored behind it: the three words of a window are
+ *              consecutive.
+ * MAIN (see k_ht_vlc): the passes where every lane is inside its block, below the first row and all blocks have an even
+ * number of quads per row run without predication.  LDS: 4 KB tables + 1 KB U-VLC + 4 waves x 64 x (18 + 9) words =
+ * exactly a fifth of a CU's 160 KB. */
+#define HT_VLC2_VPITCH 18
+#define HT_VLC2_LDS (4096 + 1024 + HT_VLC_NARROW_WAVES * 64 * (HT_VLC2_VPITCH + HT_VLC_OUT_PITCH) * 4)
+
+/* ht_uvlc_entry's fields as lp | d1 << 5 | p1 << 8 | (lp + d1) << 11 | d2 << 16 | (lp + d1 + d2) << 19 | p2 << 24 */
+__host__ __device__ inline uint32_t ht_uvlc_entry2_from(uint32_t p1, uint32_t p2, uint32_t lp, uint32_t d1, uint32_t d2)
+{
+    return lp | (d1 << 5) | (p1 << 8) | ((lp + d1) << 11) | (d2 << 16) | ((lp + d1 + d2) << 19) | (p2 << 24);
+}
+__host__ __device__ inline uint32_t ht_uvlc_entry2(int mode, uint32_t v)
+{
+    const uint32_t e = ht_uvlc_entry(mode, v);
+    return ht_uvlc_entry2_from(e & 7, (e >> 3) & 7, (e >> 6) & 7, (e >> 9) & 7, (e >> 12) & 7);
+}
+/* mode 4 (both quads of a first-row pair have an offset and the MEL symbol was 0, :666-712) without a table: the prefix
+ * of quad 1 as ever, and if it is > 2 the second value is a single bit + 1 */
+__device__ __forceinline__ uint32_t ht_uvlc_entry2_mode4(uint32_t v)
+{
+    const uint32_t b = v & 7;
+    const uint32_t p1 = (0x12131215u >> (4 * b)) & 0xF;                 /* value {5,1,2,1,3,1,2,1}, length {3,1,2,1,3,1,2,1} */
+    uint32_t lp = (0x12131213u >> (4 * b)) & 0xF, p2;
+    if (p1 > 2) { p2 = ((v >> lp) & 1) + 1; lp += 1; }
+    else { const uint32_t b2 = (v >> lp) & 7; p2 = (0x12131215u >> (4 * b2)) & 0xF; lp += (0x12131213u >> (4 * b2)) & 0xF; }
+    const uint32_t d1 = p1 < 3 ? 0u : (p1 == 3 ? 1u : 5u);
+    const uint32_t d2 = p1 > 2 ? 0u : (p2 < 3 ? 0u : (p2 == 3 ? 1u : 5u));
+    return ht_uvlc_entry2_from(p1, p2, lp, d1, d2);
+}
+
+__global__ void __launch_bounds__(64 * HT_VLC_NARROW_WAVES)
+k_ht_vlc2(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+          const uint16_t *__restrict__ g_tables, ht_sym_t *__restrict__ qsym,
+          const uint32_t *__restrict__ qoff,
+          const uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ sink)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint16_t *tbl = (uint16_t *)smem;                    /* [0, 1024): first row, index ctx << 7 | bits; [1024, 2048): the other rows */
+    uint32_t *utbl = (uint32_t *)(smem + 4096);          /* modes 0-3, 64 entries each */
+    constexpr int CAD = 8;                               /* passes per flush of the output stage */
+    constexpr int VPITCH = HT_VLC2_VPITCH, OPITCH = HT_VLC_OUT_PITCH;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *vstage = (uint32_t *)(smem + 4096 + 1024) + wv * 64 * (VPITCH + OPITCH);
+    uint32_t *ostage = vstage + 64 * VPITCH;
+    const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
+        const uint32_t e = g_tables[i], rho = (e >> 4) & 0xF;
+        const uint32_t ne = (e & 0xF) | (((rho >> 1) & 1) << 4) | (((rho >> 3) & 1) << 5) | ((((rho >> 2) | (rho >> 3)) & 1) << 6) |
+                            (ht_sym_pack_fields(rho, (e >> 8) & 0xF, (e >> 12) & 0xF) << 8);
+        const int ctx = (i >> 7) & 7, bits = i & 127;
+        const int dst = i < 1024 ? i : 1024 + (bits | ((ctx & 1) << 7) | (((ctx >> 2) & 1) << 8) | (((ctx >> 1) & 1) << 9));
+        tbl[dst] = (uint16_t)ne;
+    }
+    for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x)
+        utbl[i] = ht_uvlc_entry2(i >> 6, (uint32_t)(i & 63));
+
+    int qw = 0, qh = 0;
+    uint32_t doff = 0;
+    ht_sym_t *qout = qsym;
+    const uint8_t *mraw = bytes + 16;                    /* Dcup + Pcup: the MEL bytes; lanes without a block read the pool's front pad */
+    int mlim = 0;                                        /* Scup */
+    if (bi < nblocks) {
+        const J2kBlock b = blocks[bi];
+        bool ok = b.npasses != 0 && b.lcup >= 2;
+        uint32_t Scup = 0;
+        if (ok) {
+            const uint8_t *D = bytes + b.data_off;
+            Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
+            ok = !(Scup < 2 || Scup > b.lcup || Scup > 4079);
+        }
+        if (ok && ((b.w + 1u) >> 1) <= 32u) {
+            qw = (b.w + 1) >> 1;
+            qh = (b.h + 1) >> 1;
+            qout = qsym + qoff[bi];
+            doff = b.data_off >> 2;
+            mraw = bytes + b.data_off + (b.lcup - Scup);
+            mlim = (int)Scup;
+        }
+    }
+    const int ppr = (qw + 1) >> 1;                        /* passes per quad row */
+    const int n_it = qh * ppr;
+    int max_it = n_it;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) max_it = max(max_it, __shfl_xor(max_it, o));
+    const uint32_t my_lo = (uint32_t)(uintptr_t)qout, my_hi = (uint32_t)((uintptr_t)qout >> 32);
+    __syncthreads();
+
+    const uint32_t *vsrc = vlc_u + doff;
+    uint32_t vpos = 4;                                   /* the first 4 VLC bits are the Scup nibble (:283-295) */
+    uint32_t *vst = vstage + lane * VPITCH;
+    uint32_t *ost = ostage + lane * OPITCH;
+    /* VLC words: see k_ht_vlc.  vst[w & 15] = stream word w; vst[16], vst[17] repeat vst[0], vst[1] */
+    uint4 nxv = make_uint4(0u, 0u, 0u, 0u), nxw = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t hw = 16, pw = 0;                            /* words requested so far / word index of nxv (nxw: the four after it) */
+    bool pend = false;
+    uint64_t msyms = 0; int mcnt = 0; uint32_t mrb = 0; int mel_k = 0;     /* MEL: see k_ht_vlc */
+    uint32_t pfA, pfB, pfC;                              /* raw bytes -1 .. 10 around the next refill's position */
+    __builtin_memcpy(&pfA, mraw - 1, 4);
+    __builtin_memcpy(&pfB, mraw + 3, 4);
+    __builtin_memcpy(&pfC, mraw + 7, 4);
+    if (qh > 0) {
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++) {
+            uint4 q;
+            __builtin_memcpy(&q, vsrc + 4 * jx, 16);
+            vst[4 * jx] = q.x; vst[4 * jx + 1] = q.y; vst[4 * jx + 2] = q.z; vst[4 * jx + 3] = q.w;
+            if (jx == 0) { vst[16] = q.x; vst[17] = q.y; }
+        }
+    }
+    auto flush = [&](int win) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int c = 32 * p + (lane >> 1), part = lane & 1;
+            const uint32_t *src = ostage + c * OPITCH + 4 * part;
+            const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+            /* the symbol array and pass count of the lane that owns chunk c */
+            const uint32_t c_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_lo);
+            const uint32_t c_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_hi);
+            const uint32_t c_nit = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, n_it);
+            uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * CAD + 4 * part;
+            /* chunks of lanes that are done (or never had a block) go to a scratch line: always two stores */
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) u32x4 g_u32x4;    /* a global, not a FLAT, store */
+            u32x4 vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+            *(g_u32x4 *)(uintptr_t)((uint32_t)(win * CAD) < c_nit ? dst : sink + 4 * part) = vv;
+        }
+    };
+
+    int row = 0, qx = 0;
+    uint32_t ctx_run = 0;                                /* first row: the context the quad just decoded leaves for the next */
+    uint32_t lf10 = 0;                                   /* other rows: "the quad to the left has a significant sample on its right side", at bit 10 */
+    uint32_t Dlo = 0, Dhi = 0, Mlo = 0, Mhi = 0;         /* D: (c0, c2) of the quads from qx on, lowest first; M: (rho1, rho3) of this row's quads so far, at the top */
+    const uint8_t *tb1 = (const uint8_t *)(tbl + 1024);
+    auto pass = [&](int t, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        const bool active = MAIN || t < n_it;
+        const bool row0 = !MAIN && row == 0;
+        const bool pair = MAIN || qx + 1 < qw;
+        if ((t & 1) == 0) {
+            if (pend) {
+                uint32_t *r = vst + (pw & 15);
+                r[0] = nxv.x; r[1] = nxv.y; r[2] = nxv.z; r[3] = nxv.w;
+                if (!(pw & 15)) { vst[16] = nxv.x; vst[17] = nxv.y; }
+                r = vst + ((pw + 4) & 15);
+                r[0] = nxw.x; r[1] = nxw.y; r[2] = nxw.z; r[3] = nxw.w;
+            }
+            pend = (int)(hw - (vpos >> 5)) < 8;
+            if (pend) {
+                __builtin_memcpy(&nxv, vsrc + hw, 16);
+                __builtin_memcpy(&nxw, vsrc + hw + 4, 16);
+                pw = hw;
+                hw += 8;
+            }
+            if ((t & (CAD - 1)) == 0 && t) flush(t / CAD - 1);   /* behind the load: nothing waits for these stores */
+        }
+        if (__ballot(mcnt < 3) != 0 && mcnt <= 32) {
+            /* >= 42 MEL bits from mrb, first bit in the MSB; six codewords need <= 36.  The twelve bytes were
+             * requested at the end of the previous refill (mrb only moves here): with 64 lanes nearly every pass
+             * has some lane refilling, and a fresh load would cost the whole wave a memory round trip each time */
+            const int mb = (int)(mrb >> 3);
+            const uint32_t o = mrb & 7;
+            const uint32_t a0 = mb ? pfA : (pfA & ~0xFFu);              /* the first byte of the stream has 8 bits */
+            const uint32_t anyff = ((~a0 - 0x01010101u) & a0 & 0x80808080u) | ((~pfB - 0x01010101u) & pfB & 0x80808080u);
+            const bool slow = anyff != 0 || mb + 10 > mlim;             /* a 0xFF in bytes -1 .. 6, or the segment's end near */
+            uint64_t mw;
+            uint32_t n7 = 0;                                            /* bit j: byte j of the window has 7 bits */
+            if (!slow) {
+                const uint32_t hi = __builtin_amdgcn_perm(pfB, pfA, 0x01020304u), lo = __builtin_amdgcn_perm(pfC, pfB, 0x01020304u);
+                mw = (((uint64_t)hi << 32) | lo) << o;
+            } else {
+                uint32_t prev = 0, total = 0;
+                mw = 0;
+#pragma unroll
+                for (int j = -1; j < 7; j++) {
+                    const int p = mb + j;
+                    const uint32_t raw = ((j < 3 ? pfA >> (8 * (j + 1)) : pfB >> (8 * (j - 3)))) & 0xFF;
+                    const uint32_t v = p >= mlim - 1 ? 0xFFu : (p == mlim - 2 ? raw | 0x0Fu : raw);
+                    if (j >= 0) {
+                        const uint32_t n = prev == 0xFF ? 7u : 8u;
+                        mw = (mw << n) | (v & ((1u << n) - 1));
+                        total += n;
+                        n7 |= (8u - n) << j;
+                    }
+                    prev = p < 0 ? 0u : v;
+                }
+                mw <<= (64 - total) + (o - (n7 & 1));
+            }
+            uint32_t used_all = 0;
+#pragma unroll
+            for (int cw = 0; cw < 6; cw++) {
+                const int eval = (int)((0x5433222111000ull >> (4 * mel_k)) & 0xF);
+                const int b = (int)(mw >> 63);
+                const int run = b ? (1 << eval) : (eval ? (int)((mw << 1) >> (64 - eval)) : 0);
+                const int nsy = run + (b ? 0 : 1);
+                if (mcnt + nsy <= 64) {                  /* otherwise leave the codeword for the next refill */
+                    if (!b) msyms |= 1ull << ((mcnt + run) & 63);
+                    mcnt += nsy;
+                    const int used = b ? 1 : 1 + eval;
+                    mw <<= used; used_all += used;
+                    mel_k = b ? (mel_k < 12 ? mel_k + 1 : 12) : (mel_k > 0 ? mel_k - 1 : 0);
+                }
+            }
+            if (!slow) {
+                mrb += used_all;                                        /* lands in bytes 0 .. 5: all of 8 bits */
+            } else {
+                /* byte L of the window is the first one with bits left: cum = bits up to the end of byte j */
+                uint32_t L = 0, before = 0, cum = 8 - o;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const bool ge = used_all >= cum;
+                    L += ge;
+                    before = ge ? cum : before;
+                    cum += 8 - ((n7 >> (j + 1)) & 1);
+                }
+                mrb = L ? (uint32_t)(mb + (int)L) * 8 + ((n7 >> L) & 1) + (used_all - before) : mrb + used_all;
+            }
+            const uint8_t *pm = mraw + min((int)(mrb >> 3), mlim) - 1;
+            __builtin_memcpy(&pfA, pm, 4);
+            __builtin_memcpy(&pfB, pm + 4, 4);
+            __builtin_memcpy(&pfC, pm + 8, 4);
+        }
+        /* 64 stream bits from vpos on */
+        uint32_t lo, hi;
+        {
+            const uint32_t *wp = (const uint32_t *)((const uint8_t *)vst + ((vpos >> 3) & 60u));
+            const uint32_t a0 = wp[0], a1 = wp[1], a2 = wp[2];
+            lo = __builtin_amdgcn_alignbit(a1, a0, vpos);
+            hi = __builtin_amdgcn_alignbit(a2, a1, vpos);
+        }
+        uint32_t m = (uint32_t)msyms;                    /* next MEL symbols, LSB first */
+        uint32_t e0, e1, mused;
+        {
+            /* quad 0 */
+            const bool en0 = active;
+            uint32_t ad = row0 ? ((lo & 0x7Fu) << 1) | (ctx_run << 8)
+                               : ((lo & 0x7Fu) << 1) | ((Dlo & 3u) << 8) | lf10;
+            const uint32_t mq = (en0 && ad < 0x100u) ? 1u : 0u;
+            const uint32_t et = *(const uint16_t *)((row0 ? (const uint8_t *)tbl : tb1) + ad);
+            e0 = __umul24(et, (m | ~mq) & (MAIN ? 1u : (uint32_t)en0));          /* context 0 and MEL symbol 0: nothing coded */
+            m >>= mq; mused = mq;
+            if (row0) {
+                const uint32_t f = e0 >> 8, tt = (f | (f >> 1)) & 0x55u;          /* rho of the quad at bits 0, 2, 4, 6 */
+                if (en0) ctx_run = ((tt | (tt >> 2)) & 1u) | ((tt >> 3) & 2u) | ((tt >> 4) & 4u);
+            }
+            /* quad 1 */
+            const bool en1 = active && pair;
+            const uint32_t len0 = (e0 >> 1) & 7u;
+            const uint32_t bits1 = __builtin_amdgcn_ubfe(lo, len0, 7u) << 1;
+            ad = row0 ? bits1 | (ctx_run << 8) : bits1 | ((Dlo & 0xCu) << 6) | ((e0 & 0x40u) << 4);
+            const uint32_t mq1 = (en1 && ad < 0x100u) ? 1u : 0u;
+            const uint32_t et1 = *(const uint16_t *)((row0 ? (const uint8_t *)tbl : tb1) + ad);
+            e1 = __umul24(et1, (m | ~mq1) & (MAIN ? 1u : (uint32_t)en1));
+            m >>= mq1; mused += mq1;
+            if (row0) {
+                const uint32_t f = e1 >> 8, tt = (f | (f >> 1)) & 0x55u;
+                if (en1) ctx_run = ((tt | (tt >> 2)) & 1u) | ((tt >> 3) & 2u) | ((tt >> 4) & 4u);
+            }
+            if (MAIN || en1) lf10 = (e1 & 0x40u) << 4;
+            else if (en0) lf10 = (e0 & 0x40u) << 4;
+            /* this row's (rho bit 1, rho bit 3) pairs go into M from the top, two bits per quad decoded */
+            const uint32_t X = ((e0 >> 4) & 3u) | (((e1 >> 4) & 3u) << 2);
+            const uint32_t sh = MAIN ? 4u : 2u * ((uint32_t)en0 + (uint32_t)en1);
+            Mlo = __builtin_amdgcn_alignbit(Mhi, Mlo, sh);
+            Mhi = __builtin_amdgcn_alignbit(X, Mhi, sh);
+            Dlo = __builtin_amdgcn_alignbit(Dhi, Dlo, 4u);
+            Dhi >>= 4;
+        }
+        /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) of both quads: decode order pfx1 pfx2 sfx1 sfx2 ext1 ext2.  First
+         * row with both offsets set: one MEL symbol, 1 => both u get +2, 0 and pfx1 > 2 => u2 is a single bit + 1 */
+        const uint32_t aused = ((e0 >> 1) & 7u) + ((e1 >> 1) & 7u);
+        const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, aused);       /* <= 14 bits in: 32 bits from there, <= 24 are used */
+        uint32_t ue = utbl[(w & 63u) | ((e0 & 1u) << 6) | ((e1 & 1u) << 7)];
+        uint32_t bias = 0;
+        if (!MAIN) {
+            const bool mq2 = row0 && (e0 & e1 & 1u);
+            if (__ballot(mq2) != 0) {
+                const uint32_t mel2 = m & 1u;
+                if (mq2) {
+                    mused += 1;
+                    if (mel2) bias = 0x02000200u; else ue = ht_uvlc_entry2_mode4(w & 63u);
+                }
+            }
+        }
+        const uint32_t s1 = __builtin_amdgcn_ubfe(w, ue, __builtin_amdgcn_ubfe(ue, 5u, 3u));
+        const uint32_t s2 = __builtin_amdgcn_ubfe(w, ue >> 11, __builtin_amdgcn_ubfe(ue, 16u, 3u));
+        uint32_t uused = __builtin_amdgcn_ubfe(ue, 19u, 5u);
+        /* fields of quad 0 | u1 << 8 | fields of quad 1 << 16 | u2 << 24 */
+        uint32_t out = __builtin_amdgcn_perm(e1, e0, 0x0C050C01u) + (ue & 0x07000700u) + (s1 << 8) + (s2 << 24) + bias;
+        if (__ballot(s1 >= 28u || s2 >= 28u) != 0) {                        /* suffix extensions: u > 32 */
+            const uint32_t d1x = s1 >= 28u ? 4u : 0u, d2x = s2 >= 28u ? 4u : 0u;
+            const uint32_t x1 = __builtin_amdgcn_ubfe(w, uused, d1x), x2 = __builtin_amdgcn_ubfe(w, uused + d1x, d2x);
+            out += (x1 << 10) + (x2 << 26);
+            uused += d1x + d2x;
+        }
+        if (active) {
+            vpos += aused + uused;
+            msyms >>= mused; mcnt -= (int)mused;
+        }
+        ost[t & (CAD - 1)] = out;
+        /* next quad pair of this lane's block */
+        qx += 2;
+        if (active && qx >= qw) {
+            /* the row is done: M holds its 2 qw bits at the top; the next row's (c0, c2) pairs from them */
+            const uint64_t I = (((uint64_t)Mhi << 32) | Mlo) >> (64 - 2 * qw);
+            const uint64_t Dn = ((I | (I << 1)) & 0x5555555555555555ull) | ((I | (I >> 1)) & 0xAAAAAAAAAAAAAAAAull);
+            Dlo = (uint32_t)Dn; Dhi = (uint32_t)(Dn >> 32);
+            Mlo = 0; Mhi = 0;
+            qx = 0; row++;
+            lf10 = 0; ctx_run = 0;
+        }
+    };
+    /* [0, t_a): some lane is still in its first row; [t_a, t_b): the MAIN form; [t_b, max_it): some lane is done */
+    int t_a = ppr, t_b = n_it, odd = qw & 1;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        t_a = max(t_a, __shfl_xor(t_a, o));
+        t_b = min(t_b, __shfl_xor(t_b, o));
+        odd |= __shfl_xor(odd, o);
+    }
+    if (odd || t_b < t_a) t_a = t_b = max_it;            /* no MAIN stretch */
+    int t = 0;
+    for (; t < t_a; t++) pass(t, std::false_type{});
+    for (; t < t_b; t++) pass(t, std::true_type{});
+    for (; t < max_it; t++) pass(t, std::false_type{});
+    if (max_it > 0) flush((max_it - 1) / CAD);
+}
+
 }  // namespace htj2k

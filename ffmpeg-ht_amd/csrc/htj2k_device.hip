@@ -121,6 +121,7 @@ struct htj2k_ctx {
     int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = LDS + register/DPP tile kernel,
                                         * 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
+    int ht_vlc2 = 1;                   /* 1: launches without a block wider than 64 columns run k_ht_vlc2; 0: k_ht_vlc<true> (A/B reference) */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
     int ht_multi = 1;                  /* 1: jobs with 32-bit sub-bands whose HT blocks qualify use k_ht_decode_multi (2 or 4 blocks per wave) */
     int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
@@ -341,6 +342,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "packet_threads")) { c->packet_threads = value < 1 ? 1 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ht_vlc2")) { c->ht_vlc2 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
@@ -1381,6 +1383,12 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
                 const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
+                if (vlc_narrow && c->ht_vlc2)
+                    hipLaunchKernelGGL(k_ht_vlc2, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), HT_VLC2_LDS, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                       (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
+                                       (const uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
+                else
                 hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
