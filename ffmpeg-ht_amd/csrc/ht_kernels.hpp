@@ -49,6 +49,7 @@ struct HtLds {
 };
 
 #define HT_ERR_INVALID 1   /* the reference returns AVERROR_INVALIDDATA; block left zero */
+#define HT_REF_STRIDE 64   /* k_ht_refine's masks: 64-bit words between consecutive masks of a block (lane-interleaved per wave) */
 #define HT_MEL_SYMS  1344  /* MEL symbols a block can consume: <= 1024 quads + <= 256 first-row pairs, rounded up */
 #define HT_MEL_WORDS (HT_MEL_SYMS / 32 + 2)
 #define HT_UVLC_ENTRIES (5 * 64)
@@ -445,10 +446,10 @@ __device__ __forceinline__ int ht_magsgn_rows_narrow(const ht_sym_t *__restrict_
              * significant, its sign, MagRef bit), applied before the dequantisation: both passes work
              * on bit-plane pLSB - 1 (jpeg2000htdec.c:1309-1315, :1066-1100, :1160-1185) */
             const int qq = (pLSB - 1) & 31;
-            const uint64_t *r = rb + 6 * row;              /* rows 2 * row and 2 * row + 1 */
-            const uint64_t Rt = r[0], Gt = r[1], Qt = r[2];
+            const uint64_t *r = rb + (size_t)6 * row * HT_REF_STRIDE;   /* rows 2 * row and 2 * row + 1 (layout: k_ht_refine) */
+            const uint64_t Rt = r[0], Gt = r[HT_REF_STRIDE], Qt = r[2 * HT_REF_STRIDE];
             uint64_t Rb = 0, Gb = 0, Qb = 0;
-            if (two) { Rb = r[3]; Gb = r[4]; Qb = r[5]; }
+            if (two) { Rb = r[3 * HT_REF_STRIDE]; Gb = r[4 * HT_REF_STRIDE]; Qb = r[5 * HT_REF_STRIDE]; }
             auto refine = [&](uint32_t v, uint32_t sig, uint64_t R, uint64_t G, uint64_t Q) -> uint32_t {
                 const uint32_t nsig = (uint32_t)(R >> col) & 1u, sgn = (uint32_t)(G >> col) & 1u, mrb = (uint32_t)(Q >> col) & 1u;
                 if (nsig) v |= (1u << qq) | (1u << ((qq - 1) & 31)) | (sgn << 31);
@@ -1040,9 +1041,9 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         /* rows 2 * row and 2 * row + 1 of the refinement masks; this quad's columns are 2 q and 2 q + 1 */
         uint64_t Rt = 0, Gt = 0, Qt = 0, Rb = 0, Gb = 0, Qb = 0;
         if (REFINE && rb && row < qh) {
-            const uint64_t *r = rb + 6 * row;
-            Rt = r[0] >> (2 * q); Gt = r[1] >> (2 * q); Qt = r[2] >> (2 * q);
-            if (2 * row + 1 < h) { Rb = r[3] >> (2 * q); Gb = r[4] >> (2 * q); Qb = r[5] >> (2 * q); }
+            const uint64_t *r = rb + (size_t)6 * row * HT_REF_STRIDE;       /* (layout: k_ht_refine) */
+            Rt = r[0] >> (2 * q); Gt = r[HT_REF_STRIDE] >> (2 * q); Qt = r[2 * HT_REF_STRIDE] >> (2 * q);
+            if (2 * row + 1 < h) { Rb = r[3 * HT_REF_STRIDE] >> (2 * q); Gb = r[4 * HT_REF_STRIDE] >> (2 * q); Qb = r[5 * HT_REF_STRIDE] >> (2 * q); }
         }
         auto sample = [&](uint32_t v, int sm, uint32_t nsig, uint32_t sgn, uint32_t mrb) -> uint32_t {   /* mu (:407-427) -> dequantisation */
             uint32_t mu = (((((v >> 1) + 1u) << pLSB) | halfbit) | (v << 31)) & (uint32_t)sm;
@@ -1664,25 +1665,31 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
  * takes the next stream bit depends on the significance the previous bits created -- so, as with
  * the VLC chain, the parallelism is across blocks: 64 chains per wavefront instead of one chain
  * on lane 0 of a wavefront that idles its other 63 lanes.
- * Significance is kept as one 64-bit mask per sample row (blocks up to 64 columns; wider ones stay
- * with k_ht_decode's own serial pass): the 3x3 neighbourhood test is three shifts and an OR.
- * Input bits: the un-stuffed SigProp / MagRef arrays of k_ht_unstuff (zero bits past either end).
- * Output: three masks per row -- newly significant, its sign, MagRef bit -- which k_ht_decode
- * applies while it dequantises.  ref_list[i] = block index, roff[block] = first mask of the block. */
+ * Significance is kept as one mask per sample row (MT: 32 bits when no block of the launch is wider than 32 columns,
+ * else 64; wider blocks stay with k_ht_decode's own serial pass): the 3x3 neighbourhood test is three shifts and an OR.
+ * Input bits: the un-stuffed SigProp / MagRef arrays of k_ht_unstuff (zero bits past either end), read 16 bytes at a
+ * time with the next 16 in flight (a lane reads its own block, so every load of the wave is 64 scattered requests: with
+ * one word per load the kernel fetched 2.6 GB for 0.2 GB of stream, profiles/r02_configs_C3_C4_pmc_hbm.csv).
+ * Output: three masks per row -- newly significant, its sign, MagRef bit -- which the MagSgn kernels apply while they
+ * dequantise.  They are stored LANE-INTERLEAVED per wavefront of this kernel: mask k of row y of the block on lane l
+ * sits at refbits[roff[block] + (3 y + k) * 64], roff[block] = base of the wave + l (htj2k_device.hip: ref_layout), so
+ * that a store of the wave is 512 contiguous bytes.  ref_list[i] = block index. */
+template <typename MT>
 __global__ void __launch_bounds__(64)
 k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ ref_list, int nref,
             const uint8_t *__restrict__ bytes, const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
             const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u,
             uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
 {
+    constexpr int MB = (int)sizeof(MT) * 8;
     const int li = blockIdx.x * 64 + threadIdx.x;
     if (li >= nref) return;
     const uint32_t bi = ref_list[li];
     const J2kBlock b = blocks[bi];
     const int w = b.w, h = b.h, qw = (w + 1) >> 1, qh = (h + 1) >> 1;
     uint64_t *out = refbits + roff[bi];
-    for (int y = 0; y < 3 * h; y++) out[y] = 0;                       /* also what an invalid block leaves behind */
-    if (b.npasses == 0 || b.lcup < 2 || w > 64) return;
+    for (int y = 0; y < 3 * h; y++) out[(size_t)y * HT_REF_STRIDE] = 0;   /* also what an invalid block leaves behind */
+    if (b.npasses == 0 || b.lcup < 2 || w > MB) return;
     const uint8_t *D = bytes + b.data_off;
     const uint32_t Scup = ((uint32_t)D[b.lcup - 1] << 4) + (D[b.lcup - 2] & 0x0F);
     if (Scup < 2 || Scup > b.lcup || Scup > 4079) return;
@@ -1693,23 +1700,40 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     const ht_sym_t *qs = qsym + qoff[bi];
     const uint32_t nsw = ht_nsw(Scup), nsp = b.lref ? ht_nsp(b.lref) : 0;
     const uint32_t *spw = vlc_u + (b.data_off >> 2) + nsw, *mrw = mel_u + (b.data_off >> 2) + nsw;
-    const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+    const MT wmask = w >= MB ? (MT)~(MT)0 : (MT)(((MT)1 << w) - 1);
 
-    /* LSB-first readers over the un-stuffed arrays: a 64-bit buffer topped up a word at a time, the
-     * word for the next top-up already in flight.  Past the array: zero bits. */
+    /* LSB-first readers over the un-stuffed arrays: a 64-bit buffer topped up a word at a time out of four words in
+     * registers, the next four already requested.  Past the array: zero bits (a 16-byte piece may end up to three words
+     * behind the array: in the next block's region or the buffer's slack, masked off here). */
     struct Bits {
-        const uint32_t *p; uint32_t n, idx; uint64_t buf; int cnt; uint32_t nxt;
+        const uint32_t *p; uint32_t n, idx; uint64_t buf; int cnt; uint32_t q0, q1, q2, q3, left; uint4 nx;
+        __device__ __forceinline__ uint4 fetch(uint32_t i) const
+        {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n) {
+                __builtin_memcpy(&v, p + i, 16);
+                if (i + 1 >= n) v.y = 0;
+                if (i + 2 >= n) v.z = 0;
+                if (i + 3 >= n) v.w = 0;
+            }
+            return v;
+        }
         __device__ __forceinline__ void init(const uint32_t *q, uint32_t nw)
         {
-            p = q; n = nw; idx = 0; buf = 0; cnt = 0;
-            nxt = n ? p[0] : 0u; idx = 1;
+            p = q; n = nw; buf = 0; cnt = 0;
+            const uint4 v = fetch(0);
+            q0 = v.x; q1 = v.y; q2 = v.z; q3 = v.w; left = 4;
+            nx = fetch(4); idx = 8;
         }
         __device__ __forceinline__ void top_up()                     /* call with cnt <= 32 */
         {
-            buf |= (uint64_t)nxt << cnt;
+            buf |= (uint64_t)q0 << cnt;
             cnt += 32;
-            nxt = idx < n ? p[idx] : 0u;
-            idx++;
+            q0 = q1; q1 = q2; q2 = q3;
+            if (--left == 0) {
+                q0 = nx.x; q1 = nx.y; q2 = nx.z; q3 = nx.w; left = 4;
+                nx = fetch(idx); idx += 4;
+            }
         }
         __device__ __forceinline__ uint32_t get()
         {
@@ -1722,16 +1746,14 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
     mr.init(mrw, nsp);
 
     /* significance rows of quad row qy: the symbols of a row are read as dwords (two quads; rows are padded to an even
-     * number of quads and start on a dword), four at a time where the row pitch allows 16-byte loads -- a lane reads its
-     * own block's symbols, so every load instruction of the wave is 64 scattered requests and their number is what the
-     * kernel waits for */
+     * number of quads and start on a dword), four at a time where the row pitch allows 16-byte loads */
     const uint32_t qpitch = ht_qsym_pitch((uint32_t)w);
-    auto two_quads = [](uint32_t s2, int q, uint64_t &top, uint64_t &bot) {
+    auto two_quads = [](uint32_t s2, int q, MT &top, MT &bot) {
         const uint32_t r2 = (s2 | (s2 >> 1)) & 0x00550055u;           /* significance of sample n of quad q / q + 1 at bit 2 n / 16 + 2 n */
-        top |= (uint64_t)((r2 & 1u) | ((r2 >> 3) & 2u) | ((r2 >> 14) & 4u) | ((r2 >> 17) & 8u)) << (2 * q);            /* samples 0, 2 */
-        bot |= (uint64_t)(((r2 >> 2) & 1u) | ((r2 >> 5) & 2u) | ((r2 >> 16) & 4u) | ((r2 >> 19) & 8u)) << (2 * q);     /* samples 1, 3 */
+        top |= (MT)((r2 & 1u) | ((r2 >> 3) & 2u) | ((r2 >> 14) & 4u) | ((r2 >> 17) & 8u)) << (2 * q);            /* samples 0, 2 */
+        bot |= (MT)(((r2 >> 2) & 1u) | ((r2 >> 5) & 2u) | ((r2 >> 16) & 4u) | ((r2 >> 19) & 8u)) << (2 * q);     /* samples 1, 3 */
     };
-    auto quad_rows = [&](int qy, uint64_t &top, uint64_t &bot) {
+    auto quad_rows = [&](int qy, MT &top, MT &bot) {
         top = 0; bot = 0;
         if (qy >= qh) return;
         const uint32_t *row = (const uint32_t *)(qs + (size_t)qy * qpitch);
@@ -1750,30 +1772,30 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
         if (2 * qy + 1 >= h) bot = 0;
     };
 
-    uint64_t a_top, a_bot;
+    MT a_top, a_bot;
     quad_rows(0, a_top, a_bot);
-    uint64_t Mup = 0;                                                  /* significance of the row above the stripe, after its SigProp */
+    MT Mup = 0;                                                        /* significance of the row above the stripe, after its SigProp */
     for (int i0 = 0; i0 < h; i0 += 4) {
-        uint64_t b_top, b_bot, c_top, c_bot;
+        MT b_top, b_bot, c_top, c_bot;
         quad_rows(i0 / 2 + 1, b_top, b_bot);
         quad_rows(i0 / 2 + 2, c_top, c_bot);
-        const uint64_t S0 = a_top, S1 = a_bot, S2 = b_top, S3 = b_bot, S4 = c_top;
-        uint64_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0, Q0 = 0, Q1 = 0, Q2 = 0, Q3 = 0;
+        const MT S0 = a_top, S1 = a_bot, S2 = b_top, S3 = b_bot, S4 = c_top;
+        MT R0 = 0, R1 = 0, R2 = 0, R3 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0, Q0 = 0, Q1 = 0, Q2 = 0, Q3 = 0;
         const int gh = min(4, h - i0);
         /* SigProp (:1016-1100).  A sample is a candidate when the cleanup pass left it insignificant and one of its eight
-         * neighbours is significant.  The neighbours split into what the cleanup pass decided -- per row one 64-bit mask
+         * neighbours is significant.  The neighbours split into what the cleanup pass decided -- per row one mask
          * T_i, made once per stripe: the rows above and below smeared by a column either way, the row itself shifted --
          * and what this pass has decided so far, which at column j is only column j - 1 (all rows: `rprev`) and the rows
          * above in column j itself (`rcur`): two 4-bit values.  The masks are shifted along with the column, so that a
          * sample costs a handful of 32-bit operations instead of three variable 64-bit shifts. */
         {
-            auto smear = [](uint64_t x) -> uint64_t { return x | (x << 1) | (x >> 1); };
+            auto smear = [](MT x) -> MT { return x | (MT)(x << 1) | (x >> 1); };
             const bool dn0 = !causal || gh != 1, dn1 = !causal || gh != 2, dn2 = !causal || gh != 3, dn3 = !causal || gh != 4;
-            uint64_t s0 = S0, s1 = S1, s2 = S2, s3 = S3;
-            uint64_t T0 = smear(Mup) | (S0 << 1) | (S0 >> 1) | (dn0 ? smear(S1) : 0ull);
-            uint64_t T1 = smear(S0) | (S1 << 1) | (S1 >> 1) | (dn1 ? smear(S2) : 0ull);
-            uint64_t T2 = smear(S1) | (S2 << 1) | (S2 >> 1) | (dn2 ? smear(S3) : 0ull);
-            uint64_t T3 = smear(S2) | (S3 << 1) | (S3 >> 1) | (dn3 ? smear(S4) : 0ull);
+            MT s0 = S0, s1 = S1, s2 = S2, s3 = S3;
+            MT T0 = smear(Mup) | (MT)(S0 << 1) | (S0 >> 1) | (dn0 ? smear(S1) : (MT)0);
+            MT T1 = smear(S0) | (MT)(S1 << 1) | (S1 >> 1) | (dn1 ? smear(S2) : (MT)0);
+            MT T2 = smear(S1) | (MT)(S2 << 1) | (S2 >> 1) | (dn2 ? smear(S3) : (MT)0);
+            MT T3 = smear(S2) | (MT)(S3 << 1) | (S3 >> 1) | (dn3 ? smear(S4) : (MT)0);
             const uint32_t m0 = dn0 ? 7u : 3u, m1 = dn1 ? 7u : 3u, m2 = dn2 ? 7u : 3u, m3 = dn3 ? 7u : 3u;
             uint32_t rprev = 0;
             for (int j0 = 0; j0 < w; j0 += 4) {
@@ -1789,8 +1811,8 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
                         if (gh > 1 && !((uint32_t)s1 & 1u) && ((((uint32_t)T1 & 1u) | ((RP >> 1) & m1) | (rcur & 1u)) != 0) && sp.get()) rcur |= 2u;
                         if (gh > 2 && !((uint32_t)s2 & 1u) && ((((uint32_t)T2 & 1u) | ((RP >> 2) & m2) | (rcur & 2u)) != 0) && sp.get()) rcur |= 4u;
                         if (gh > 3 && !((uint32_t)s3 & 1u) && ((((uint32_t)T3 & 1u) | ((RP >> 3) & m3) | (rcur & 4u)) != 0) && sp.get()) rcur |= 8u;
-                        R0 |= (uint64_t)(rcur & 1u) << j; R1 |= (uint64_t)((rcur >> 1) & 1u) << j;
-                        R2 |= (uint64_t)((rcur >> 2) & 1u) << j; R3 |= (uint64_t)(rcur >> 3) << j;
+                        R0 |= (MT)(rcur & 1u) << j; R1 |= (MT)((rcur >> 1) & 1u) << j;
+                        R2 |= (MT)((rcur >> 2) & 1u) << j; R3 |= (MT)(rcur >> 3) << j;
                         rc4[jj] = rcur;
                         rprev = rcur;
                         s0 >>= 1; s1 >>= 1; s2 >>= 1; s3 >>= 1;
@@ -1803,10 +1825,10 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
                     const int j = j0 + jj;
                     const uint32_t r = rc4[jj];
                     if (j < w && r) {
-                        if (r & 1u) G0 |= (uint64_t)sp.get() << j;
-                        if (r & 2u) G1 |= (uint64_t)sp.get() << j;
-                        if (r & 4u) G2 |= (uint64_t)sp.get() << j;
-                        if (r & 8u) G3 |= (uint64_t)sp.get() << j;
+                        if (r & 1u) G0 |= (MT)sp.get() << j;
+                        if (r & 2u) G1 |= (MT)sp.get() << j;
+                        if (r & 4u) G2 |= (MT)sp.get() << j;
+                        if (r & 8u) G3 |= (MT)sp.get() << j;
                     }
                 }
             }
@@ -1814,46 +1836,20 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
         if (z_blk > 2) {                                               /* MagRef: one bit per sample the cleanup pass made significant */
             for (int j = 0; j < w; j++) {
                 if (mr.cnt <= 32) mr.top_up();
-                if ((S0 >> j) & 1) Q0 |= (uint64_t)mr.get() << j;
-                if ((S1 >> j) & 1) Q1 |= (uint64_t)mr.get() << j;
-                if ((S2 >> j) & 1) Q2 |= (uint64_t)mr.get() << j;
-                if ((S3 >> j) & 1) Q3 |= (uint64_t)mr.get() << j;
+                if ((S0 >> j) & 1) Q0 |= (MT)mr.get() << j;
+                if ((S1 >> j) & 1) Q1 |= (MT)mr.get() << j;
+                if ((S2 >> j) & 1) Q2 |= (MT)mr.get() << j;
+                if ((S3 >> j) & 1) Q3 |= (MT)mr.get() << j;
             }
         }
-        uint64_t *o = out + 3 * i0;
-        if (gh > 3) {                                                  /* the stripe's 96 bytes as six 16-byte stores (a lane writes its own block:
-                                                                        * every store instruction of the wave is 64 scattered requests) */
-            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-            typedef u64x2 u64x2_a8 __attribute__((aligned(8)));
-            u64x2 v;
-            v.x = R0; v.y = G0; *(u64x2_a8 *)(o + 0) = v;
-            v.x = Q0; v.y = R1; *(u64x2_a8 *)(o + 2) = v;
-            v.x = G1; v.y = Q1; *(u64x2_a8 *)(o + 4) = v;
-            v.x = R2; v.y = G2; *(u64x2_a8 *)(o + 6) = v;
-            v.x = Q2; v.y = R3; *(u64x2_a8 *)(o + 8) = v;
-            v.x = G3; v.y = Q3; *(u64x2_a8 *)(o + 10) = v;
-        } else {
-            o[0] = R0; o[1] = G0; o[2] = Q0;
-            if (gh > 1) { o[3] = R1; o[4] = G1; o[5] = Q1; }
-            if (gh > 2) { o[6] = R2; o[7] = G2; o[8] = Q2; }
-        }
+        uint64_t *o = out + (size_t)3 * i0 * HT_REF_STRIDE;            /* a store of the wave: the 64 lanes' masks, 512 contiguous bytes */
+        o[0] = R0; o[HT_REF_STRIDE] = G0; o[2 * HT_REF_STRIDE] = Q0;
+        if (gh > 1) { o[3 * HT_REF_STRIDE] = R1; o[4 * HT_REF_STRIDE] = G1; o[5 * HT_REF_STRIDE] = Q1; }
+        if (gh > 2) { o[6 * HT_REF_STRIDE] = R2; o[7 * HT_REF_STRIDE] = G2; o[8 * HT_REF_STRIDE] = Q2; }
+        if (gh > 3) { o[9 * HT_REF_STRIDE] = R3; o[10 * HT_REF_STRIDE] = G3; o[11 * HT_REF_STRIDE] = Q3; }
         Mup = S3 | R3;
         a_top = c_top; a_bot = c_bot;
     }
-}
-
-struct Win128 { uint32_t w0, w1, w2, w3; uint32_t base; };   /* base = word index of w0 */
-
-__device__ __forceinline__ uint64_t vlc_window(const Win128 &W, uint32_t pos)
-{
-    /* 64 stream bits starting at bit `pos` (LSB-first); pos - 32*base is in [0, 70] */
-    const uint32_t off = pos - (W.base << 5);
-    const uint32_t k = off >> 5, sh = off & 31;
-    const uint32_t a = k == 0 ? W.w0 : (k == 1 ? W.w1 : W.w2);
-    const uint32_t b = k == 0 ? W.w1 : (k == 1 ? W.w2 : W.w3);
-    const uint32_t c = k == 0 ? W.w2 : (k == 1 ? W.w3 : 0u);
-    const uint64_t lo = ((uint64_t)b << 32) | a;
-    return sh ? ((lo >> sh) | ((uint64_t)c << (64 - sh))) : lo;
 }
 
 /* U-VLC prefix table (T.814 7.3.6 / jpeg2000htdec.c:338-352, 666-712): index = mode * 64 + 6 stream

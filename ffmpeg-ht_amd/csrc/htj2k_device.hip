@@ -210,6 +210,7 @@ struct htj2k_job {
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
     size_t nrefmasks = 0;
+    uint32_t ref_max_w = 0;            /* widest block of reflist: k_ht_refine keeps 32-bit row masks when it is at most 32 */
     uint32_t max_lref = 0;
     size_t nquads = 0;
     HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
@@ -685,6 +686,33 @@ static int ht_lds_layout(htj2k_ctx *c, uint32_t max_p, uint32_t max_s, uint32_t 
     return 0;
 }
 
+/* Which blocks k_ht_refine handles (SigProp / MagRef passes, at most 64 columns, no ROI shift) and where their masks
+ * go: the block on lane l of the kernel's wave g (reflist[64 g + l]) has mask k of row y at
+ * roff[block] + (3 y + k) * HT_REF_STRIDE, roff[block] = base of wave g + l; a wave takes 64 * 3 * (its tallest block)
+ * words.  Returns the total in 64-bit words; *max_w = the widest such block. */
+static size_t ref_layout(const J2kBlock *blocks, size_t nblocks, std::vector<uint32_t> &reflist, std::vector<uint32_t> &roff, uint32_t *max_w)
+{
+    reflist.clear();
+    roff.assign(nblocks + 1, 0);
+    *max_w = 0;
+    for (size_t i = 0; i < nblocks; i++) {
+        const J2kBlock &b = blocks[i];
+        const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+        if (b.npasses && !(b.flags & J2K_BLK_PART1) && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
+            reflist.push_back((uint32_t)i);
+            if (b.w > *max_w) *max_w = b.w;
+        }
+    }
+    size_t nm = 0;
+    for (size_t g = 0; g < reflist.size(); g += 64) {
+        uint32_t hmax = 0;
+        for (size_t l = g; l < std::min(g + 64, reflist.size()); l++) hmax = std::max<uint32_t>(hmax, blocks[reflist[l]].h);
+        for (size_t l = g; l < std::min(g + 64, reflist.size()); l++) roff[reflist[l]] = (uint32_t)(nm + (l - g));
+        nm += (size_t)HT_REF_STRIDE * 3 * hmax;
+    }
+    return nm;
+}
+
 static void push_bytes(std::vector<uint8_t> &v, const void *p, size_t n)
 {
     const uint8_t *b = (const uint8_t *)p;
@@ -1008,18 +1036,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         j->nquads = q;
         /* blocks with SigProp / MagRef passes go through k_ht_refine (one lane per block) when
          * k_ht_decode's row-mask path can take them: up to 64 columns, no ROI shift */
-        j->reflist.clear();
-        j->roff.assign(j->blocks.size() + 1, 0);
-        size_t nm = 0;
-        for (size_t i = 0; i < j->blocks.size(); i++) {
-            const J2kBlock &b = j->blocks[i];
-            const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
-            j->roff[i] = (uint32_t)nm;
-            if (b.npasses && !(b.flags & J2K_BLK_PART1) && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
-                j->reflist.push_back((uint32_t)i);
-                nm += (size_t)3 * b.h;
-            }
-        }
+        const size_t nm = ref_layout(j->blocks.data(), j->blocks.size(), j->reflist, j->roff, &j->ref_max_w);
         if (nm > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
         j->nrefmasks = nm;
     }
@@ -1394,7 +1411,7 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
                 if (!j->reflist.empty())
-                    hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
+                    hipLaunchKernelGGL(j->ref_max_w <= 32 ? k_ht_refine<uint32_t> : k_ht_refine<uint64_t>, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, (const uint32_t *)j->d_reflist.p, (int)j->reflist.size(),
                                        (const uint8_t *)j->d_bytes.p, (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
@@ -2053,19 +2070,10 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
         if (b.npasses) nq += ht_qsym_words(b.w, b.h);
     }
     /* blocks with refinement passes that k_ht_refine handles (same rule as htj2k_job_upload) */
-    std::vector<uint32_t> reflist, roff(nblocks + 1, 0);
-    size_t nmasks = 0;
-    uint32_t max_lref = 0;
-    for (int i = 0; i < nblocks; i++) {
-        const J2kBlock &b = ((const J2kBlock *)blocks)[i];
-        const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
-        roff[i] = (uint32_t)nmasks;
-        if (b.lref > max_lref) max_lref = b.lref;
-        if (b.npasses && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
-            reflist.push_back((uint32_t)i);
-            nmasks += (size_t)3 * b.h;
-        }
-    }
+    std::vector<uint32_t> reflist, roff;
+    uint32_t max_lref = 0, ref_max_w = 0;
+    for (int i = 0; i < nblocks; i++) max_lref = std::max<uint32_t>(max_lref, ((const J2kBlock *)blocks)[i].lref);
+    const size_t nmasks = ref_layout((const J2kBlock *)blocks, (size_t)nblocks, reflist, roff, &ref_max_w);
     DevBuf db, dby, dc, ds, dq, dqo, du[2], drl, dro, drb;
     auto release_all = [&]() {
         db.release(); dby.release(); dc.release(); ds.release(); dq.release(); dqo.release(); du[0].release(); du[1].release();
@@ -2104,7 +2112,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (ht_sym_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq / 2 + 32);
             if (!reflist.empty())
-                hipLaunchKernelGGL(k_ht_refine, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
+                hipLaunchKernelGGL(ref_max_w <= 32 ? k_ht_refine<uint32_t> : k_ht_refine<uint64_t>, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
                                    (const J2kBlock *)db.p, (const uint32_t *)drl.p, (int)reflist.size(), (const uint8_t *)dby.p,
                                    (const ht_sym_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p,
                                    (uint64_t *)drb.p, (const uint32_t *)dro.p);
