@@ -138,6 +138,7 @@ struct htj2k_ctx {
     int device_gather = 1;             /* 1: the packets are uploaded as they are and k_gather puts the byte pool together on the
                                         * device (the parser does not touch code-block bytes); 0: the parser gathers on the host */
     std::mutex log_mutex;
+    std::atomic<int> refs{1};          /* the caller's, + one per pipe that is still open or has device frames out (htj2k_pipe.cpp) */
 };
 
 struct LevelLaunch {                   /* one IDWT launch: all planes (of all frames) of one type that have this level */
@@ -158,6 +159,7 @@ struct FrameSlot {                     /* one frame of a batch */
     const J2kPlan *plan = nullptr;
     HostBuf h_pkt;                     /* device gather: the packet staged in pinned memory (the caller's is only borrowed for the call) */
     const uint8_t *h2d_src = nullptr;  /* ... or the caller's packet itself when that is page-locked (htj2k_job_parse_batch_ex) */
+    bool h2d_own = false;              /* h2d_src is h_pkt (64 bytes of zero padding behind the packet) */
     size_t pkt_base = 0;               /* ... and where it goes in d_pkt */
     HostBuf h_bytes;                   /* host gather: the parser gathers the codeblock bytes straight into pinned memory */
     float ms_stage = 0, ms_parse = 0;  /* host time of the last parse_batch: staging copy, parser */
@@ -207,6 +209,7 @@ struct htj2k_job {
     std::vector<uint32_t> ggroups;
     std::vector<uint8_t> lit;
     size_t pkt_bytes = 0;
+    bool pkt_h2d_issued = false;       /* htj2k_job_parse_batch has sent the packets on their way already: the next upload does not */
     std::vector<uint32_t> qoff;        /* first quad of every (sorted) block in d_qsym */
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
     size_t nrefmasks = 0;
@@ -216,6 +219,7 @@ struct htj2k_job {
     HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
     uint32_t max_qw = 1;
     std::vector<uint8_t> h_desc;       /* host image of d_desc: level tables + pack tiles */
+    std::vector<uint8_t> h_desc_dev;   /* ... and what d_desc holds (empty after a parse: the tables are rebuilt and d_desc may move) */
     std::vector<LevelLaunch> launches_generic, launches_tile;
     std::vector<LevelLaunch> launches_fused;   /* idwt_mode 3 with the pack stage fused into the final level */
     std::vector<uint8_t> tile_fusable;         /* per PackTile */
@@ -398,8 +402,13 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
     delete j;
 }
 
+/* a pipe keeps its context alive: htj2k_close by the caller while a closed pipe still has device frames out (reference-
+ * counted frames may outlive the decoder) must not free what those frames' release path needs */
+extern "C" void htj2k_ctx_ref_(htj2k_ctx *c) { if (c) c->refs.fetch_add(1); }
+
 extern "C" void htj2k_close(htj2k_ctx *c)
 {
+    if (c && c->refs.fetch_sub(1) != 1) return;            /* the last reference frees */
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_job) htj2k_job_free(c, c->own_job);
@@ -436,6 +445,17 @@ static int job_new(htj2k_ctx *c, htj2k_job **out)
  * tables are then concatenated (offsets re-based into one device arena) so that each stage
  * of the whole batch is a single launch: frames are independent, so a batch is simply a
  * longer codeblock table, more planes per IDWT level, more tiles to pack. */
+/* one packet -> its place in d_pkt, asynchronously on the job's stream.  A staging copy of ours carries its 64 bytes of zero
+ * padding; a caller's page-locked packet is read up to its last byte only and the padding is set on the device (k_gather reads
+ * whole dwords, up to 3 bytes past a segment) */
+static hipError_t job_packet_h2d(htj2k_job *j, const FrameSlot &F, size_t size)
+{
+    uint8_t *dst = (uint8_t *)j->d_pkt.p + F.pkt_base;
+    hipError_t e = hipMemcpyAsync(dst, F.h2d_src, size + (F.h2d_own ? 64 : 0), hipMemcpyHostToDevice, j->stream);
+    if (e == hipSuccess && !F.h2d_own) e = hipMemsetAsync(dst + size, 0, 64, j->stream);
+    return e;
+}
+
 extern "C" int htj2k_job_parse_batch(htj2k_ctx *c, const uint8_t *const *pkts, const int *sizes, int n, htj2k_job **job)
 {
     return htj2k_job_parse_batch_ex(c, pkts, sizes, n, nullptr, job);
@@ -476,47 +496,80 @@ extern "C" int htj2k_job_parse_batch_ex(htj2k_ctx *c, const uint8_t *const *pkts
                                    &F.h_bytes);
         F.plan = nullptr;
     }
-    /* frames are independent: parse them on several host threads */
+    /* frames are independent: stage and parse them on several host threads */
     {
         std::vector<int> rc(n, 0);
         int nthreads = c->parse_threads > 0 ? c->parse_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (nthreads > n) nthreads = n;
-        std::atomic<int> next(0);
-        const bool stage = j->dev_gather;
-        auto work = [&]() {
-            for (;;) {
-                const int f = next.fetch_add(1);
-                if (f >= n) break;
-                FrameSlot &F = j->frames[f];
-                const uint8_t *src = pkts[f];
-                const auto t0 = std::chrono::steady_clock::now();
-                F.h2d_src = nullptr;
-                if (stage && pinned && pinned[f]) {
-                    F.h2d_src = src;                        /* page-locked and stable: the upload reads the packet itself */
-                } else if (stage) {
-                    const size_t sz = sizes[f] > 0 ? (size_t)sizes[f] : 0;
-                    uint8_t *h = (uint8_t *)F.h_pkt.ensure(sz + 64);
-                    if (!h) { rc[f] = HTJ2K_ERR_ENOMEM; continue; }
-                    memcpy(h, src, sz);
-                    memset(h + sz, 0, 64);
-                    src = h;
-                    F.h2d_src = h;
+        auto parallel_frames = [&](auto &&fn) {
+            std::atomic<int> next(0);
+            auto work = [&]() {
+                for (;;) {
+                    const int f = next.fetch_add(1);
+                    if (f >= n) break;
+                    fn(f);
                 }
-                const auto t1 = std::chrono::steady_clock::now();
-                rc[f] = j2k_parse(F.parser, src, sizes[f], &c->opts, 0, &F.plan);
-                const auto t2 = std::chrono::steady_clock::now();
-                F.ms_stage = std::chrono::duration<float, std::milli>(t1 - t0).count();
-                F.ms_parse = std::chrono::duration<float, std::milli>(t2 - t1).count();
+            };
+            if (nthreads <= 1) {
+                work();
+            } else {
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+                work();
+                for (std::thread &t : pool) t.join();
             }
         };
-        if (nthreads <= 1) {
-            work();
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
-            work();
-            for (std::thread &t : pool) t.join();
+        const bool stage = j->dev_gather;
+        /* 1. device gather: every packet into page-locked memory (unless the caller's already is) ... */
+        std::vector<const uint8_t *> src(pkts, pkts + n);
+        if (stage)
+            parallel_frames([&](int f) {
+                FrameSlot &F = j->frames[f];
+                const auto t0 = std::chrono::steady_clock::now();
+                F.h2d_src = nullptr;
+                F.h2d_own = false;
+                if (pinned && pinned[f]) {
+                    F.h2d_src = src[f];                     /* page-locked and stable: the upload reads the packet itself */
+                } else {
+                    const size_t sz = sizes[f] > 0 ? (size_t)sizes[f] : 0;
+                    uint8_t *h = (uint8_t *)F.h_pkt.ensure(sz + 64);
+                    if (!h) { rc[f] = HTJ2K_ERR_ENOMEM; return; }
+                    memcpy(h, src[f], sz);
+                    memset(h + sz, 0, 64);
+                    src[f] = h;
+                    F.h2d_src = h;
+                    F.h2d_own = true;
+                }
+                F.ms_stage = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            });
+        for (int f = 0; f < n; f++)
+            if (rc[f] < 0) return rc[f];
+        /* 2. ... and on its way to the device BEFORE it is parsed: where a packet goes in d_pkt follows from the sizes
+         * alone, and the parser needs nothing from the device, so the transfer of a frame (0.35 ms for a 4K frame) runs
+         * under its parse (0.36 ms) instead of behind it */
+        j->pkt_h2d_issued = false;
+        if (stage) {
+            size_t total = 0;
+            bool fits = true;
+            for (int f = 0; f < n; f++) {
+                j->frames[f].pkt_base = total;
+                total += ((size_t)(sizes[f] > 0 ? sizes[f] : 0) + 64 + 15) & ~(size_t)15;
+                if (total > 0xFFFFFF00ull) fits = false;
+            }
+            if (fits && hipSetDevice(c->device) == hipSuccess && j->d_pkt.ensure(total + 256) == 0) {
+                bool ok = true;
+                for (int f = 0; f < n && ok; f++) ok = job_packet_h2d(j, j->frames[f], sizes[f] > 0 ? (size_t)sizes[f] : 0) == hipSuccess;
+                j->pkt_h2d_issued = ok;
+            }
         }
+        /* 3. parse */
+        parallel_frames([&](int f) {
+            FrameSlot &F = j->frames[f];
+            const auto t1 = std::chrono::steady_clock::now();
+            rc[f] = j2k_parse(F.parser, src[f], sizes[f], &c->opts, 0, &F.plan);
+            F.ms_parse = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            if (!stage) F.ms_stage = 0;
+        });
         for (int f = 0; f < n; f++)
             if (rc[f] < 0) return rc[f];                   /* the first failing frame in submission order */
     }
@@ -552,6 +605,7 @@ extern "C" int htj2k_job_parse_batch_ex(htj2k_ctx *c, const uint8_t *const *pkts
             if (pkt_bytes + (size_t)pl->pkt_size > 0xFFFFFF00ull || j->lit.size() + pl->nlit > 0xFFFFFF00ull ||
                 j->gsegs.size() + pl->nsegs > 0xFFFFFF00ull)
                 return HTJ2K_ERR_PATCHWELCOME;
+            if (F.pkt_base != pkt_bytes) j->pkt_h2d_issued = false;   /* (cannot happen: same formula as above) */
             F.pkt_base = pkt_bytes;
             const uint32_t lit_base = (uint32_t)j->lit.size(), seg_base = (uint32_t)j->gsegs.size();
             for (uint32_t k = 0; k < pl->nsegs; k++) {
@@ -724,6 +778,7 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
 {
     const int ntc = (int)j->tilecomps.size();
     j->h_desc.clear();
+    j->h_desc_dev.clear();                              /* d_desc is written again by the next run */
     j->launches_generic.clear();
     j->launches_tile.clear();
     j->final_buf.assign(ntc, 0);
@@ -1138,11 +1193,10 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         if ((r = j->d_pkt.ensure(j->pkt_bytes + 256)) < 0 || (r = j->d_lit.ensure(j->lit.size() + 64)) < 0 ||
             (r = j->d_gsegs.ensure((j->gsegs.size() + 1) * sizeof(J2kSeg))) < 0 ||
             (r = j->d_ggroups.ensure((j->ggroups.size() + 1) * sizeof(uint32_t))) < 0) return r;
-        for (int f = 0; f < j->nframes; f++) {
-            const FrameSlot &F = j->frames[f];
-            HIP_TRY(c, hipMemcpyAsync((uint8_t *)j->d_pkt.p + F.pkt_base, F.h2d_src, (size_t)F.plan->pkt_size + 64,
-                                      hipMemcpyHostToDevice, j->stream));
-        }
+        if (!j->pkt_h2d_issued)
+            for (int f = 0; f < j->nframes; f++)
+                HIP_TRY(c, job_packet_h2d(j, j->frames[f], (size_t)j->frames[f].plan->pkt_size));
+        j->pkt_h2d_issued = false;
         if (!j->lit.empty())
             HIP_TRY(c, hipMemcpyAsync(j->d_lit.p, j->lit.data(), j->lit.size(), hipMemcpyHostToDevice, j->stream));
         if (!j->gsegs.empty())
@@ -1484,7 +1538,12 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
             }
         }
         if (!(mask & 1)) HIP_TRY(c, hipEventRecord(j->ev[3], j->stream));
-        HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
+        /* the tables only change with the knobs (which buffer a plane ends in, fused or not): a run whose tables are what the
+         * device already holds uploads nothing -- a pageable copy in the middle of the stream, once per step, otherwise */
+        if (j->h_desc != j->h_desc_dev) {
+            HIP_TRY(c, hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size(), hipMemcpyHostToDevice, j->stream));
+            j->h_desc_dev = j->h_desc;
+        }
         if (mask & 2) {
             /* coef16_ok has checked that every level of every plane is a FASTONLY streaming launch and every plane ends fused */
             j->ll16_run = c->ll16 && j->coef_is16 && fuse && use_tile && !j->force_ll32;

@@ -14,6 +14,7 @@
  * the same per-packet error behaviour as the synchronous htj2k_decode().
  */
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -22,6 +23,8 @@
 #include <string.h>
 
 #include "../../include/htj2k_amd.h"
+
+extern "C" void htj2k_ctx_ref_(htj2k_ctx *ctx);     /* htj2k_device.hip: one more htj2k_close is needed to free the context */
 
 namespace {
 
@@ -49,6 +52,7 @@ struct Slot {
     bool device_handout = false;       /* some frame of the batch left as device pointers */
     long release_at = 0;               /* SLOT_HELD: free again once this many batches have been handed out in full */
     int outstanding = 0;               /* device frames handed out by htj2k_pipe_receive_device_ref and not released yet */
+    std::vector<uint8_t> ref_out;      /* ... which ones (by position in the batch): a token releases its own frame, once */
     uint32_t generation = 0;           /* bumped every time the slot is started: stale release tokens are ignored */
     std::vector<htj2k_job *> retry;    /* failed batch, device hand-out: one single-frame job per frame (the pointers stay valid
                                         * as long as the slot's) */
@@ -60,13 +64,20 @@ struct Slot {
 struct htj2k_pipe {
     htj2k_ctx *ctx = nullptr;
     int batch = 1, depth = 2;
+    /* 2 depth - 1 slots: `depth` batches may be in flight (being filled, running or waiting to be received) while up to
+     * depth - 1 more are HELD because their frames went out as device pointers.  (With `depth` slots in a strict ring a
+     * consumer of device frames had ONE batch in flight: a slot came free only when the batches behind it had been
+     * received, so the next batch could not even start before that -- 1 300 frames per second where PCIe carries 2 700.)
+     * A new batch takes any FREE slot; frames still come out in the order their packets went in (`started`). */
     std::vector<Slot> slots;
-    int fill = 0, out = 0;             /* ring positions: slot being filled / slot being handed out */
+    int cur = -1;                      /* slot being filled, -1: none */
+    std::deque<int> started;           /* slots in the order their batches were started: the front one is handed out */
     std::mutex m;
     std::condition_variable cv;
     htj2k_job *single = nullptr;       /* per-frame retry of a failed batch */
     std::vector<PinBuf> spare;         /* packet buffers waiting for re-use */
     long batches_out = 0;              /* batches whose frames have all been handed out */
+    bool closing = false;              /* htj2k_pipe_close was called while device frames were out: the last release frees */
 };
 
 /* caller holds the lock */
@@ -104,6 +115,7 @@ static void start_slot(htj2k_pipe *p, Slot &s)
     s.next_out = 0;
     s.device_handout = false;
     s.outstanding = 0;
+    s.ref_out.clear();
     s.generation++;
     if (s.worker.joinable()) s.worker.join();
     s.worker = std::thread(run_slot, p, &s);
@@ -115,22 +127,38 @@ extern "C" int htj2k_pipe_open(htj2k_ctx *ctx, int batch, int depth, htj2k_pipe 
     htj2k_pipe *p = new (std::nothrow) htj2k_pipe();
     if (!p) return HTJ2K_ERR_ENOMEM;
     p->ctx = ctx;
+    htj2k_ctx_ref_(ctx);               /* given back by the last act of htj2k_pipe_close (which may come after the caller's htj2k_close) */
     p->batch = batch;
     p->depth = depth;
-    p->slots.resize(depth);
+    p->slots.resize((size_t)(2 * depth - 1));
     *pipe = p;
     return 0;
 }
 
-static int queue_packet(htj2k_pipe *p, const Packet &pk)
+/* caller holds the lock.  The slot a packet goes into: the one being filled, or a FREE one if fewer than `depth` batches
+ * are in flight; nullptr: receive first (HTJ2K_ERR_EAGAIN) */
+static Slot *fill_slot(htj2k_pipe *p)
 {
-    Slot &s = p->slots[p->fill];
+    if (p->cur >= 0) return &p->slots[(size_t)p->cur];
+    if ((int)p->started.size() >= p->depth) return nullptr;
+    for (size_t i = 0; i < p->slots.size(); i++)
+        if (p->slots[i].state == SLOT_FREE) { p->cur = (int)i; return &p->slots[i]; }
+    return nullptr;
+}
+
+/* caller holds the lock */
+static void start_current(htj2k_pipe *p)
+{
+    start_slot(p, p->slots[(size_t)p->cur]);
+    p->started.push_back(p->cur);
+    p->cur = -1;
+}
+
+static int queue_packet(htj2k_pipe *p, Slot &s, const Packet &pk)
+{
     s.pkts.push_back(pk);
     s.state = SLOT_FILLING;
-    if ((int)s.pkts.size() >= p->batch) {
-        start_slot(p, s);
-        p->fill = (p->fill + 1) % p->depth;
-    }
+    if ((int)s.pkts.size() >= p->batch) start_current(p);
     return 0;
 }
 
@@ -138,8 +166,8 @@ extern "C" int htj2k_pipe_send(htj2k_pipe *p, const uint8_t *pkt, int size)
 {
     if (!p || !pkt || size <= 0) return HTJ2K_ERR_EINVAL;
     std::unique_lock<std::mutex> lk(p->m);
-    Slot &s = p->slots[p->fill];
-    if (s.state != SLOT_FREE && s.state != SLOT_FILLING) return HTJ2K_ERR_EAGAIN;      /* receive first */
+    Slot *sp = fill_slot(p);
+    if (!sp) return HTJ2K_ERR_EAGAIN;                      /* receive first */
     /* private copy with the input padding an AVPacket carries (AV_INPUT_BUFFER_PADDING_SIZE), in page-locked memory:
      * the H2D transfer starts from this very copy */
     Packet pk;
@@ -159,7 +187,7 @@ extern "C" int htj2k_pipe_send(htj2k_pipe *p, const uint8_t *pkt, int size)
     memset(pk.own.p + size, 0, PIPE_PAD);
     pk.data = pk.own.p;
     pk.size = size;
-    return queue_packet(p, pk);
+    return queue_packet(p, *sp, pk);
 }
 
 /* no copy: `pkt` stays valid until `release(opaque)` is called, which happens when the packet's
@@ -168,34 +196,29 @@ extern "C" int htj2k_pipe_send_ref(htj2k_pipe *p, const uint8_t *pkt, int size, 
 {
     if (!p || !pkt || size <= 0) return HTJ2K_ERR_EINVAL;
     std::unique_lock<std::mutex> lk(p->m);
-    Slot &s = p->slots[p->fill];
-    if (s.state != SLOT_FREE && s.state != SLOT_FILLING) return HTJ2K_ERR_EAGAIN;
+    Slot *sp = fill_slot(p);
+    if (!sp) return HTJ2K_ERR_EAGAIN;
     Packet pk;
     pk.data = pkt;
     pk.size = size;
     pk.release = release;
     pk.opaque = opaque;
-    return queue_packet(p, pk);
+    return queue_packet(p, *sp, pk);
 }
 
 extern "C" int htj2k_pipe_flush(htj2k_pipe *p)
 {
     if (!p) return HTJ2K_ERR_EINVAL;
     std::unique_lock<std::mutex> lk(p->m);
-    Slot &s = p->slots[p->fill];
-    if (s.state == SLOT_FILLING) {
-        start_slot(p, s);
-        p->fill = (p->fill + 1) % p->depth;
-    }
+    if (p->cur >= 0 && p->slots[(size_t)p->cur].state == SLOT_FILLING) start_current(p);
     return 0;
 }
 
 /* the slot whose frame is due; waits for its job.  HTJ2K_ERR_EAGAIN: nothing is in flight (send or flush first) */
 static int due_slot(htj2k_pipe *p, std::unique_lock<std::mutex> &lk, Slot **out)
 {
-    Slot &s = p->slots[p->out];
-    /* (HELD: its frames are all out and the consumer still has some of them; nothing behind it can have been started) */
-    if (s.state == SLOT_FREE || s.state == SLOT_FILLING || s.state == SLOT_HELD) return HTJ2K_ERR_EAGAIN;
+    if (p->started.empty()) return HTJ2K_ERR_EAGAIN;
+    Slot &s = p->slots[(size_t)p->started.front()];
     p->cv.wait(lk, [&] { return s.state == SLOT_DONE; });
     *out = &s;
     return 0;
@@ -220,7 +243,7 @@ static void pop_frame(htj2k_pipe *p, Slot &s)
         }
         for (Slot &o : p->slots)
             if (o.state == SLOT_HELD && p->batches_out >= o.release_at && o.outstanding == 0) o.state = SLOT_FREE;
-        p->out = (p->out + 1) % p->depth;
+        p->started.pop_front();
     }
 }
 
@@ -293,7 +316,7 @@ extern "C" int htj2k_pipe_receive_device(htj2k_pipe *p, htj2k_frame *frame)
 extern "C" int htj2k_pipe_receive_device_ref(htj2k_pipe *p, htj2k_frame *frame, uint64_t *token)
 {
     if (!p || !frame || !token) return HTJ2K_ERR_EINVAL;
-    int slot_index = 0;
+    int slot_index = 0, frame_index = 0;
     uint32_t gen = 0;
     {
         std::unique_lock<std::mutex> lk(p->m);
@@ -301,32 +324,58 @@ extern "C" int htj2k_pipe_receive_device_ref(htj2k_pipe *p, htj2k_frame *frame, 
         int r = due_slot(p, lk, &s);
         if (r < 0) return r;
         slot_index = (int)(s - p->slots.data());
+        frame_index = s->next_out;
         gen = s->generation;
         s->outstanding++;                                  /* before the hand-out: pop_frame must see it */
+        if ((int)s->ref_out.size() <= frame_index) s->ref_out.resize((size_t)frame_index + 1, 0);
+        s->ref_out[(size_t)frame_index] = 1;
     }
     const int r = htj2k_pipe_receive_device(p, frame);
     std::unique_lock<std::mutex> lk(p->m);
     Slot &s = p->slots[(size_t)slot_index];
     if (r < 0) {
-        if (s.generation == gen && s.outstanding > 0) s.outstanding--;
+        if (s.generation == gen && s.outstanding > 0) { s.outstanding--; s.ref_out[(size_t)frame_index] = 0; }
         if (s.state == SLOT_HELD && s.outstanding == 0 && p->batches_out >= s.release_at) s.state = SLOT_FREE;
         return r;
     }
     s.release_at = 0;                                      /* explicit release rules this slot, not the depth - 1 rule */
     if (s.state == SLOT_HELD && s.outstanding == 0) s.state = SLOT_FREE;
-    *token = ((uint64_t)(uint32_t)slot_index << 32) | gen;
+    *token = ((uint64_t)(uint32_t)slot_index << 48) | ((uint64_t)((uint32_t)frame_index & 0xFFFFu) << 32) | gen;
     return r;
+}
+
+/* caller holds no lock.  What htj2k_pipe_close leaves for later when device frames are still out */
+static void destroy_pipe(htj2k_pipe *p)
+{
+    for (Slot &s : p->slots) {
+        if (s.job) htj2k_job_free(p->ctx, s.job);
+        for (htj2k_job *j : s.retry) if (j) htj2k_job_free(p->ctx, j);
+    }
+    if (p->single) htj2k_job_free(p->ctx, p->single);
+    for (PinBuf &b : p->spare) htj2k_host_free(p->ctx, b.p);
+    htj2k_ctx *ctx = p->ctx;
+    delete p;
+    htj2k_close(ctx);                  /* the pipe's reference */
 }
 
 extern "C" int htj2k_pipe_release_device(htj2k_pipe *p, uint64_t token)
 {
     if (!p) return HTJ2K_ERR_EINVAL;
-    std::unique_lock<std::mutex> lk(p->m);
-    const size_t idx = (size_t)(token >> 32);
-    if (idx >= p->slots.size()) return HTJ2K_ERR_EINVAL;
-    Slot &s = p->slots[idx];
-    if (s.generation != (uint32_t)token || s.outstanding <= 0) return HTJ2K_ERR_EINVAL;
-    if (--s.outstanding == 0 && s.state == SLOT_HELD && p->batches_out >= s.release_at) s.state = SLOT_FREE;
+    bool last = false;
+    {
+        std::unique_lock<std::mutex> lk(p->m);
+        const size_t idx = (size_t)(token >> 48), fi = (size_t)((token >> 32) & 0xFFFFu);
+        if (idx >= p->slots.size()) return HTJ2K_ERR_EINVAL;
+        Slot &s = p->slots[idx];
+        if (s.generation != (uint32_t)token || s.outstanding <= 0 || fi >= s.ref_out.size() || !s.ref_out[fi]) return HTJ2K_ERR_EINVAL;
+        s.ref_out[fi] = 0;
+        if (--s.outstanding == 0 && s.state == SLOT_HELD && p->batches_out >= s.release_at) s.state = SLOT_FREE;
+        if (p->closing) {
+            last = true;
+            for (const Slot &o : p->slots) if (o.outstanding > 0) last = false;
+        }
+    }
+    if (last) destroy_pipe(p);         /* closed long ago: this was the last frame the consumer held */
     return 0;
 }
 
@@ -342,17 +391,26 @@ extern "C" int htj2k_pipe_skip(htj2k_pipe *p)
     return 0;
 }
 
+/* Frames handed out by htj2k_pipe_receive_device_ref may outlive the pipe (and the context: the pipe holds a reference):
+ * with such frames out, close stops the workers and drops what is queued, and the last htj2k_pipe_release_device frees the
+ * jobs -- the planes the consumer still reads -- and the pipe itself.  The handle stays valid for that call only. */
 extern "C" void htj2k_pipe_close(htj2k_pipe *p)
 {
     if (!p) return;
-    for (Slot &s : p->slots) {
+    for (Slot &s : p->slots)
         if (s.worker.joinable()) s.worker.join();
-        if (s.job) htj2k_job_free(p->ctx, s.job);
-        for (htj2k_job *j : s.retry) if (j) htj2k_job_free(p->ctx, j);
-        for (size_t i = (s.state == SLOT_FREE || s.state == SLOT_HELD ? s.pkts.size() : (size_t)s.next_out); i < s.pkts.size(); i++)
-            drop_packet(p, s.pkts[i]);
+    bool out = false;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        for (Slot &s : p->slots) {
+            for (size_t i = (s.state == SLOT_FREE || s.state == SLOT_HELD ? s.pkts.size() : (size_t)s.next_out); i < s.pkts.size(); i++)
+                drop_packet(p, s.pkts[i]);
+            s.pkts.clear();
+            if (s.outstanding > 0) { out = true; s.state = SLOT_HELD; s.release_at = 0; }
+        }
+        p->started.clear();
+        p->cur = -1;
+        p->closing = out;
     }
-    if (p->single) htj2k_job_free(p->ctx, p->single);
-    for (PinBuf &b : p->spare) htj2k_host_free(p->ctx, b.p);
-    delete p;
+    if (!out) destroy_pipe(p);
 }

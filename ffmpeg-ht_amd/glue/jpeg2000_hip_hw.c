@@ -46,13 +46,15 @@ typedef struct HipHwContext {
 } HipHwContext;
 
 /* one per frame in the consumer's hands: gives the planes back to the pipe when the last reference goes */
-typedef struct HipFrameRef { htj2k_pipe *pipe; uint64_t token; AVBufferRef *pipe_owner; } HipFrameRef;
+typedef struct HipFrameRef { htj2k_pipe *pipe; uint64_t token; } HipFrameRef;
 
 static void frame_released(void *opaque, uint8_t *data)
 {
     HipFrameRef *r = opaque;
-    htj2k_pipe_release_device(r->pipe, r->token);      /* any thread; the batch's job may be reused after the last one */
-    av_buffer_unref(&r->pipe_owner);                   /* keeps the pipe alive while frames are out (see hw_close) */
+    /* any thread; the batch's job may be reused after the last one.  Also after hw_close: a pipe that is closed with
+     * frames out stays behind (with its jobs -- the planes -- and a reference on the context) until the last of them
+     * is released here (include/htj2k_amd.h, htj2k_pipe_close) */
+    htj2k_pipe_release_device(r->pipe, r->token);
     av_free(r);
 }
 
@@ -184,8 +186,9 @@ static av_cold int hw_close(AVCodecContext *avctx)
     HipHwContext *s = avctx->priv_data;
     av_packet_free(&s->held);
     av_buffer_unref(&s->frames_ref);
-    /* every AV_PIX_FMT_HIP frame must have been released by now (FFmpeg frees decoder output before closing the
-     * decoder in its own pipelines; API users get the same rule as for *_cuvid) */
+    /* AV_PIX_FMT_HIP frames may outlive the decoder (ordinary API use: avcodec_free_context with frames still referenced):
+     * htj2k_pipe_close defers freeing the jobs those frames' planes belong to, and the context they were made on, until
+     * frame_released() has given the last one back */
     if (s->pipe) htj2k_pipe_close(s->pipe);
     htj2k_close(s->ctx);
     return 0;

@@ -287,18 +287,23 @@ int  htj2k_pipe_flush(htj2k_pipe *pipe);
 int  htj2k_pipe_info(htj2k_pipe *pipe, htj2k_info *info);
 int  htj2k_pipe_receive(htj2k_pipe *pipe, htj2k_frame *out);
 /* as htj2k_pipe_receive without the copy: `out->data[]` are the device pointers of the decoded planes; they stay
- * valid until the pipe has handed out all frames of `depth - 1` further batches: the batch's job is kept back that
- * long (htj2k_pipe_send answers HTJ2K_ERR_EAGAIN when it would need it), so a consumer of device frames has
- * `depth - 1` batches in flight, not `depth` */
+ * valid until the pipe has handed out all frames of `depth - 1` further batches.  The pipe keeps 2 depth - 1 jobs for
+ * this: `depth` batches in flight and the depth - 1 most recent ones whose frames are out */
 int  htj2k_pipe_receive_device(htj2k_pipe *pipe, htj2k_frame *out);
 /* the same for consumers that keep frames for as long as they like (reference-counted frames: the AV_PIX_FMT_HIP
  * hand-out of glue/jpeg2000_hip_hw.c): the planes stay valid until htj2k_pipe_release_device(token) -- callable from
- * any thread, e.g. an AVBuffer free callback; until then the batch's job is not reused.  A consumer that sits on
- * frames of all `depth` batches starves the pipe (htj2k_pipe_send keeps answering HTJ2K_ERR_EAGAIN): size `depth`
- * for the frames the consumer holds, as extra_hw_frames does for hardware decoders. */
+ * any thread, e.g. an AVBuffer free callback; a token releases its own frame, once.  Until all frames of a batch are
+ * released its job is not reused; the other jobs go on (a new batch takes any free job, frames still come out in the
+ * order their packets went in).  A consumer that sits on frames of 2 depth - 1 batches starves the pipe (htj2k_pipe_send
+ * answers HTJ2K_ERR_EAGAIN and nothing is in flight): size `depth` for the frames the consumer holds, as
+ * extra_hw_frames does for hardware decoders. */
 int  htj2k_pipe_receive_device_ref(htj2k_pipe *pipe, htj2k_frame *out, uint64_t *token);
 int  htj2k_pipe_release_device(htj2k_pipe *pipe, uint64_t token);
 int  htj2k_pipe_skip(htj2k_pipe *pipe);
+/* Stops the workers, drops what is queued and frees the pipe -- unless frames handed out by
+ * htj2k_pipe_receive_device_ref are still out: then the jobs they live in, the pipe and the context (the pipe holds a
+ * reference: an htj2k_close by the caller does not free it yet) stay until the last htj2k_pipe_release_device, the only
+ * call the handle is still good for.  Frames may so outlive the decoder that made them. */
 void htj2k_pipe_close(htj2k_pipe *pipe);
 
 /* ---- framing: cutting a byte stream of back-to-back frames into packets ----------------------------

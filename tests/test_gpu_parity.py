@@ -1091,6 +1091,47 @@ def test_two_devices_in_one_process(orc):
         assert all(np.array_equal(a, b) for a, b in zip(results[i], want[i])), i
 
 
+def test_device_frames_outlive_the_pipe_and_the_decoder(orc):
+    """reference-counted device frames (htj2k_pipe_receive_device_ref) may outlive the decoder, as AVFrames may outlive
+    avcodec_free_context: htj2k_pipe_close with frames out defers freeing their jobs, and the pipe's reference keeps the
+    context behind htj2k_close; the last htj2k_pipe_release_device frees everything; a token works once"""
+    import ffmpeg_ht_amd as m
+    names = ["rgb_mct", "gray_l5_cb64", "yuv420p8"]
+    pkts = [streams.get(n)[0] for n in names] * 2
+    want = [orc.decode(p)[1] for p in pkts[:len(names)]]
+    d1 = m.Decoder()
+    pipe = d1.pipe(batch=2, depth=2)
+    held = []
+    sent = 0
+    while len(held) < len(pkts):
+        while sent < len(pkts) and pipe.send(pkts[sent]):
+            sent += 1
+        if sent == len(pkts):
+            pipe.flush()
+        info = m.Info()
+        r = d1.L.htj2k_pipe_info(pipe.h, ctypes.byref(info))
+        assert r >= 0                                          # 2 * depth - 1 = 3 jobs of 2 frames: all six can be out
+        fr, tok = pipe.receive_device_ref()
+        held.append((len(held), info, fr, tok))
+    L, ph = d1.L, pipe.h
+    pipe.close()                                              # frames are out: deferred
+    d1.close()                                                # the caller's reference; the pipe still holds one
+    d2 = m.Decoder()                                          # (a device pointer is good in any context of the process)
+    try:
+        for k, (i, inf, fr, tok) in enumerate(held):
+            got = d2.fetch_device_frame(inf, fr)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want[k % len(names)])), k
+        for k, (i, inf, fr, tok) in enumerate(held):
+            assert L.htj2k_pipe_release_device(ph, ctypes.c_uint64(tok)) == 0
+            if k + 1 < len(held):
+                assert L.htj2k_pipe_release_device(ph, ctypes.c_uint64(tok)) == -22   # a token releases its frame once
+        # (the last release freed the pipe: the handle must not be used again)
+        info, planes, _, st = d2.decode(pkts[0])             # the device is fine
+        assert st.n_block_errors == 0
+    finally:
+        d2.close()
+
+
 def test_pipe_device_frames_with_explicit_release(dec, orc):
     """htj2k_pipe_receive_device_ref / htj2k_pipe_release_device (what a reference-counted AV_PIX_FMT_HIP frame needs):
     frames held across many later batches keep their pixels; a consumer sitting on frames of every batch gets EAGAIN
