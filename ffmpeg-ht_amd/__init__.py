@@ -408,10 +408,11 @@ class Pipe:
 class Decoder:
     """htj2k_open / htj2k_probe / htj2k_decode / htj2k_close: the FFCodec init/decode/close trio."""
 
-    def __init__(self, device_id=0, bitexact=0, reduction_factor=0, req_pix_fmt=-1, strict=0, max_pixels=0):
+    def __init__(self, device_id=0, bitexact=0, reduction_factor=0, req_pix_fmt=-1, strict=0, max_pixels=0, frames_in_flight=0):
         self.L = load_library()
         o = Opts()
         o.device_id = device_id
+        o.frames_in_flight = frames_in_flight
         o.bitexact = bitexact
         o.reduction_factor = reduction_factor
         o.req_pix_fmt = req_pix_fmt

@@ -405,6 +405,12 @@ extern "C" void htj2k_job_free(htj2k_ctx *c, htj2k_job *j)
 /* a pipe keeps its context alive: htj2k_close by the caller while a closed pipe still has device frames out (reference-
  * counted frames may outlive the decoder) must not free what those frames' release path needs */
 extern "C" void htj2k_ctx_ref_(htj2k_ctx *c) { if (c) c->refs.fetch_add(1); }
+/* htj2k_opts.frames_in_flight: the pipeline depth of a pipe opened with depth 0 */
+extern "C" int htj2k_ctx_default_depth_(const htj2k_ctx *c)
+{
+    const int d = c ? c->opts.frames_in_flight : 0;
+    return d <= 0 ? 3 : (d > 16 ? 16 : d);
+}
 
 extern "C" void htj2k_close(htj2k_ctx *c)
 {

@@ -25,6 +25,7 @@
 #include "../../include/htj2k_amd.h"
 
 extern "C" void htj2k_ctx_ref_(htj2k_ctx *ctx);     /* htj2k_device.hip: one more htj2k_close is needed to free the context */
+extern "C" int htj2k_ctx_default_depth_(const htj2k_ctx *ctx);   /* htj2k_opts.frames_in_flight */
 
 namespace {
 
@@ -123,6 +124,7 @@ static void start_slot(htj2k_pipe *p, Slot &s)
 
 extern "C" int htj2k_pipe_open(htj2k_ctx *ctx, int batch, int depth, htj2k_pipe **pipe)
 {
+    if (ctx && depth == 0) depth = htj2k_ctx_default_depth_(ctx);
     if (!ctx || !pipe || batch < 1 || batch > 256 || depth < 1 || depth > 16) return HTJ2K_ERR_EINVAL;
     htj2k_pipe *p = new (std::nothrow) htj2k_pipe();
     if (!p) return HTJ2K_ERR_ENOMEM;

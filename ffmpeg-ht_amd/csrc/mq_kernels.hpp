@@ -131,6 +131,9 @@ struct MqLane {
 /*
  * One lane per codeblock.  blocks: the Part-1 table (first block of wave g at waves[g] order: 64 * g).
  */
+/* (64, 4): 128 VGPRs, 47 / 70 of them spilled to scratch.  (64, 3) compiles without spills (152 / 168 VGPRs) and is SLOWER:
+ * 5.24 against 6.17 Gpixel/s on bench.py --part1 80 (round 3, gpurun_out/r03/bench_p1_lb3.log) -- the lockstep decoder step
+ * waits on LDS and scratch either way, and a fourth wave per SIMD hides more of it than the spills cost. */
 template <bool WIDE>                                                 /* WIDE: some block of the launch has more than 64 columns */
 __global__ void __launch_bounds__(64, 4)
 k_mq_decode(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,

@@ -66,7 +66,8 @@ typedef struct htj2k_opts {
     int64_t max_pixels;    /* avctx->max_pixels (jpeg2000dec.c:224); 0 = INT_MAX */
     int strict;            /* strict_std_compliance >= FF_COMPLIANCE_STRICT (jpeg2000dec.c:2488) */
     int device_id;         /* HIP device ordinal */
-    int frames_in_flight;  /* device-side pipeline depth (streams); 0 = default (2) */
+    int frames_in_flight;  /* device-side pipeline depth: the `depth` of htj2k_pipe_open when that is called with depth 0
+                            * (batches in flight, each on a HIP stream of its own); 0 = default (3) */
     int req_pix_fmt;       /* avctx->pix_fmt preset by the caller, or HTJ2K_PIX_NONE (jpeg2000dec.c:354) */
 } htj2k_opts;
 
@@ -278,6 +279,7 @@ int   htj2k_device_to_host(htj2k_ctx *ctx, void *dst, const void *device_src, si
  *   htj2k_pipe_skip     drops the next frame
  * One producer/consumer thread at a time may use a pipe (like an AVCodecContext). */
 typedef struct htj2k_pipe htj2k_pipe;
+/* batch: 1 .. 256 frames per device job; depth: 1 .. 16 jobs in flight, 0 = htj2k_opts.frames_in_flight */
 int  htj2k_pipe_open(htj2k_ctx *ctx, int batch, int depth, htj2k_pipe **pipe);
 int  htj2k_pipe_send(htj2k_pipe *pipe, const uint8_t *pkt, int size);
 /* as htj2k_pipe_send without the copy: `pkt` (with its 64 bytes of input padding) stays valid until

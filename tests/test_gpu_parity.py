@@ -1091,6 +1091,27 @@ def test_two_devices_in_one_process(orc):
         assert all(np.array_equal(a, b) for a, b in zip(results[i], want[i])), i
 
 
+def test_frames_in_flight_is_the_default_pipe_depth(orc):
+    """htj2k_opts.frames_in_flight: a pipe opened with depth 0 keeps that many batches in flight"""
+    import ffmpeg_ht_amd as m
+    data = streams.get("gray_l5_cb64")[0]
+    want = orc.decode(data)[1]
+    for fif, expect in ((1, 1), (4, 4), (0, 3)):
+        d = m.Decoder(frames_in_flight=fif)
+        pipe = d.pipe(batch=1, depth=0)
+        try:
+            accepted = 0
+            while accepted < 20 and pipe.send(data):          # nothing is received: send stops when `depth` batches wait
+                accepted += 1
+            assert accepted == expect, (fif, accepted)
+            for _ in range(accepted):
+                info, planes = pipe.receive()
+                assert all(np.array_equal(a, b) for a, b in zip(planes, want))
+        finally:
+            pipe.close()
+            d.close()
+
+
 def test_device_frames_outlive_the_pipe_and_the_decoder(orc):
     """reference-counted device frames (htj2k_pipe_receive_device_ref) may outlive the decoder, as AVFrames may outlive
     avcodec_free_context: htj2k_pipe_close with frames out defers freeing their jobs, and the pipe's reference keeps the
