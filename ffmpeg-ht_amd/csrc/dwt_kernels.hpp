@@ -20,14 +20,12 @@
  * Kernel families (htj2k_set_int "idwt_mode"):
  *   3  k_idwt_stream / k_idwt_stream_pack (dwt_stream.hpp, default): register-streaming, no
  *      LDS; the final level fused with the inverse MCT and the frame store
- *   2  k_idwt_tile2: a workgroup reconstructs an output tile; horizontal lifting in registers
- *      (DPP) on the way into LDS, vertical lifting in registers on the way out
- *   1  k_idwt_tile: the four sub-band tiles staged through LDS, lifting in LDS; also the
- *      fallback for lines of a single sample
+ *   1  k_idwt_tile: the four sub-band tiles staged through LDS, lifting in LDS: what the
+ *      streaming kernels hand lines of a single sample to
  *   0  k_idwt_h / k_idwt_v: any geometry, one closed-form output per thread, row pass into a
- *      scratch plane then column pass back (2 reads + 2 writes per level)
- * All four are bit-identical; the lower modes are kept as A/B references and for degenerate
- * geometry.
+ *      scratch plane then column pass back (2 reads + 2 writes per level): planes with more
+ *      levels than their size allows, and the definition the others are tested against
+ * All are bit-identical.  (Round 1's second LDS family, k_idwt_tile2, was an A/B reference only and is gone.)
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -312,23 +310,7 @@ k_idwt_tile(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ l
 }
 
 
-/* ================================================================== fused tile kernel, 2nd generation
- * Same contract as k_idwt_tile (LL from `ll`, HL/LH/HH from `band`, output never aliases an
- * input), different execution:
- *   phase 1  one wavefront per staged row: lane l owns the even position A0+2l (a low-pass
- *            coefficient) and the odd position A0+2l+1 (a high-pass one), loaded with two
- *            coalesced 256-byte reads through per-lane column indices that already contain the
- *            symmetric reflection (computed once per tile).  Horizontal lifting runs entirely in
- *            registers, the neighbour operand comes from lane-1 / lane+1 by DPP wave shifts.
- *            Nothing special happens at the ends of the staged row: with HALO (+1) extra
- *            positions on each side the valid region just shrinks onto the tile.  The
- *            (even, odd) pair goes to LDS with one 8-byte write.
- *   phase 2  one thread per pair of columns and 16 output rows: the staged column is read from
- *            LDS (8-byte reads, conflict-free), the vertical lifting runs sequentially in
- *            registers (staged row 0 sits on an even absolute row, so parities are compile-time),
- *            and the rows are written with 8-byte stores (512 contiguous bytes per wave).
- * One barrier per tile; every coefficient is read once (plus ~10 % halo), every output written once.
- * Lines of a single sample (lh == 1 or lv == 1) are left to k_idwt_tile. */
+/* lane-to-lane moves of the streaming kernels (dwt_stream.hpp) */
 __device__ __forceinline__ uint32_t dpp_from_left(uint32_t v)    /* lane i <- lane i-1, lane 0 <- 0 */
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);    /* wave_shr:1 */
@@ -336,197 +318,6 @@ __device__ __forceinline__ uint32_t dpp_from_left(uint32_t v)    /* lane i <- la
 __device__ __forceinline__ uint32_t dpp_from_right(uint32_t v)   /* lane i <- lane i+1, lane 63 <- 0 */
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);    /* wave_shl:1 */
-}
-
-template <int TYPE> struct Lift;
-template <> struct Lift<J2K_DWT53> {
-    static constexpr int HALO = 2;
-    /* e: even (low) sample, o: odd (high) sample of one position pair; l = odd to the left,
-     * r = even to the right (taken after the even step) */
-    template <class GetL, class GetR>
-    static __device__ __forceinline__ void run(uint32_t &e, uint32_t &o, GetL left_odd, GetR right_even)
-    {
-        e -= (uint32_t)((int)(left_odd(o) + o + 2u) >> 2);        /* jpeg2000dwt.c:321-322 */
-        o += (uint32_t)((int)(e + right_even(e)) >> 1);           /* :323-324 */
-    }
-};
-template <> struct Lift<J2K_DWT97> {
-    static constexpr int HALO = 4;
-    template <class GetL, class GetR>
-    static __device__ __forceinline__ void run(uint32_t &eu, uint32_t &ou, GetL left_odd, GetR right_even)
-    {
-        float e = __uint_as_float(eu), o = __uint_as_float(ou);
-        e -= F_DELTA * (__uint_as_float(left_odd(__float_as_uint(o))) + o);        /* :390-391 */
-        o -= F_GAMMA * (e + __uint_as_float(right_even(__float_as_uint(e))));      /* :393-394 */
-        e += F_BETA  * (__uint_as_float(left_odd(__float_as_uint(o))) + o);        /* :396-397 */
-        o += F_ALPHA * (e + __uint_as_float(right_even(__float_as_uint(e))));      /* :399-400 */
-        eu = __float_as_uint(e); ou = __float_as_uint(o);
-    }
-};
-template <> struct Lift<J2K_DWT97_INT> {
-    static constexpr int HALO = 4;
-    template <class GetL, class GetR>
-    static __device__ __forceinline__ void run(uint32_t &eu, uint32_t &ou, GetL left_odd, GetR right_even)
-    {
-        int32_t e = (int32_t)eu, o = (int32_t)ou;
-        e -= (int32_t)((I_DELTA * ((int32_t)left_odd((uint32_t)o) + (int64_t)o) + (1 << 15)) >> 16);     /* :467-468 */
-        o -= (int32_t)((I_GAMMA * (e + (int64_t)(int32_t)right_even((uint32_t)e)) + (1 << 15)) >> 16);   /* :470-471 */
-        e += (int32_t)((I_BETA  * ((int32_t)left_odd((uint32_t)o) + (int64_t)o) + (1 << 15)) >> 16);     /* :473-474 */
-        {
-            const int64_t sum = e + (int64_t)(int32_t)right_even((uint32_t)e);                             /* :476-480 */
-            o += (int32_t)sum;
-            o += (int32_t)((I_ALPHA_PRIME * sum + (1 << 15)) >> 16);
-        }
-        eu = (uint32_t)e; ou = (uint32_t)o;
-    }
-};
-
-template <int TYPE>
-__global__ void __launch_bounds__(256, 4)      /* LDS admits 4 workgroups per CU: keep the registers within that */
-k_idwt_tile2(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
-             const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base)
-{
-    constexpr int HALO = Lift<TYPE>::HALO;
-    constexpr int SW = 128;                         /* staged positions per row = 2 per lane */
-    constexpr int TW = SW - 2 * HALO - 2;           /* even, so tile origins keep the parity of mh */
-    constexpr int TH = 64;
-    constexpr int SH = TH + 2 * HALO + 2;
-    constexpr int RPT = TH / 4;                     /* output rows per thread in phase 2 */
-    constexpr int NR = RPT + 2 * HALO + 2;          /* staged rows a thread reads (even count start) */
-    __shared__ __align__(16) uint32_t tile[SH * SW];
-
-    const DwtTileArgs A = args[blockIdx.z];
-    const DwtLevel g = A.g;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    if (x0 >= g.lh || y0 >= g.lv) return;
-    const LineMap LX(g.mh, g.lh), LY(g.mv, g.lv);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t *ll = ll_base + A.ll_off, *band = band_base + g.plane_off;
-
-    /* staged origin: even absolute positions at or below (tile origin - HALO) */
-    const int ax0 = (g.mh + x0 - HALO) & ~1, ay0 = (g.mv + y0 - HALO) & ~1;
-
-    /* ---- phase 1: load + horizontal lifting, one wave per staged row ---- */
-    {
-        const int pe = ax0 + 2 * lane, po = pe + 1;                  /* absolute positions of this lane */
-        /* positions further than HALO+2 outside the line are never needed by a valid output */
-        const bool use_e = pe >= g.mh - HALO - 2 && pe < g.mh + g.lh + HALO + 2;
-        const bool use_o = po >= g.mh - HALO - 2 && po < g.mh + g.lh + HALO + 2;
-        const int ce = use_e ? LX.idx(pe) : 0, co = use_o ? LX.idx(po) : 0;    /* storage columns (reflected) */
-        /* all loads of this wave's rows are issued before the first one is consumed: ~9 KB in
-         * flight per wave instead of 512 B */
-        constexpr int RPW = (SH + 3) / 4;                /* staged rows per wave */
-        const int w0 = __builtin_amdgcn_readfirstlane(wave);
-        uint32_t ev[RPW], ov[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; r++) {
-            const int sy = w0 + 4 * r;
-            const int ay = ay0 + sy;
-            ev[r] = 0; ov[r] = 0;
-            if (sy < SH && ay >= g.mv - HALO - 2 && ay < g.mv + g.lv + HALO + 2) {        /* wave-uniform */
-                const int iy = (ay >= LY.i0 && ay < LY.i1) ? ((ay & 1) ? LY.nl + ((ay - LY.fo) >> 1) : ((ay - LY.fe) >> 1))
-                                                           : LY.idx(ay);
-                const bool lowy = iy < LY.nl;
-                const uint32_t *erow = lowy ? ll + (size_t)iy * A.ll_stride : band + (size_t)iy * g.stride;
-                const uint32_t *orow = band + (size_t)iy * g.stride;
-                if (use_e) ev[r] = erow[ce];
-                if (use_o) ov[r] = orow[co];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; r++) {
-            const int sy = w0 + 4 * r;
-            if (sy >= SH) continue;
-            uint32_t e = ev[r], o = ov[r];
-            Lift<TYPE>::run(e, o, [](uint32_t v) { return dpp_from_left(v); }, [](uint32_t v) { return dpp_from_right(v); });
-            *(uint2 *)&tile[sy * SW + 2 * lane] = make_uint2(e, o);
-        }
-    }
-    __syncthreads();
-
-    /* ---- phase 2: vertical lifting in registers, 2 columns x RPT rows per thread ---- */
-    {
-        const int c = lane, grp = wave;
-        /* first staged row this thread needs: output rows [y0 + grp*RPT, +RPT) start at staged row
-         * (g.mv + y0 - ay0) + grp*RPT; go HALO back and down to an even row */
-        const int sy_first = ((g.mv + y0 - ay0) + grp * RPT - HALO) & ~1;
-        uint32_t v0[NR], v1[NR];
-#pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int sy = sy_first + k;
-            uint2 q = make_uint2(0u, 0u);
-            if (sy < SH) q = *(const uint2 *)&tile[sy * SW + 2 * c];
-            v0[k] = q.x; v1[k] = q.y;
-        }
-        /* staged row sy_first is at an even absolute row: v[even k] are low rows, v[odd k] high rows */
-        if (TYPE == J2K_DWT53) {
-#pragma unroll
-            for (int k = 2; k < NR - 1; k += 2) {
-                v0[k] -= (uint32_t)((int)(v0[k - 1] + v0[k + 1] + 2u) >> 2);
-                v1[k] -= (uint32_t)((int)(v1[k - 1] + v1[k + 1] + 2u) >> 2);
-            }
-#pragma unroll
-            for (int k = 3; k < NR - 2; k += 2) {
-                v0[k] += (uint32_t)((int)(v0[k - 1] + v0[k + 1]) >> 1);
-                v1[k] += (uint32_t)((int)(v1[k - 1] + v1[k + 1]) >> 1);
-            }
-        } else if (TYPE == J2K_DWT97) {
-            auto F = [](uint32_t u) { return __uint_as_float(u); };
-            auto U = [](float f) { return __float_as_uint(f); };
-#pragma unroll
-            for (int k = 2; k < NR - 1; k += 2) { v0[k] = U(F(v0[k]) - F_DELTA * (F(v0[k - 1]) + F(v0[k + 1]))); v1[k] = U(F(v1[k]) - F_DELTA * (F(v1[k - 1]) + F(v1[k + 1]))); }
-#pragma unroll
-            for (int k = 3; k < NR - 2; k += 2) { v0[k] = U(F(v0[k]) - F_GAMMA * (F(v0[k - 1]) + F(v0[k + 1]))); v1[k] = U(F(v1[k]) - F_GAMMA * (F(v1[k - 1]) + F(v1[k + 1]))); }
-#pragma unroll
-            for (int k = 4; k < NR - 3; k += 2) { v0[k] = U(F(v0[k]) + F_BETA * (F(v0[k - 1]) + F(v0[k + 1]))); v1[k] = U(F(v1[k]) + F_BETA * (F(v1[k - 1]) + F(v1[k + 1]))); }
-#pragma unroll
-            for (int k = 5; k < NR - 4; k += 2) { v0[k] = U(F(v0[k]) + F_ALPHA * (F(v0[k - 1]) + F(v0[k + 1]))); v1[k] = U(F(v1[k]) + F_ALPHA * (F(v1[k - 1]) + F(v1[k + 1]))); }
-        } else {
-            auto I = [](uint32_t u) { return (int32_t)u; };
-#pragma unroll
-            for (int k = 2; k < NR - 1; k += 2) {
-                v0[k] = (uint32_t)(I(v0[k]) - (int32_t)((I_DELTA * (I(v0[k - 1]) + (int64_t)I(v0[k + 1])) + (1 << 15)) >> 16));
-                v1[k] = (uint32_t)(I(v1[k]) - (int32_t)((I_DELTA * (I(v1[k - 1]) + (int64_t)I(v1[k + 1])) + (1 << 15)) >> 16));
-            }
-#pragma unroll
-            for (int k = 3; k < NR - 2; k += 2) {
-                v0[k] = (uint32_t)(I(v0[k]) - (int32_t)((I_GAMMA * (I(v0[k - 1]) + (int64_t)I(v0[k + 1])) + (1 << 15)) >> 16));
-                v1[k] = (uint32_t)(I(v1[k]) - (int32_t)((I_GAMMA * (I(v1[k - 1]) + (int64_t)I(v1[k + 1])) + (1 << 15)) >> 16));
-            }
-#pragma unroll
-            for (int k = 4; k < NR - 3; k += 2) {
-                v0[k] = (uint32_t)(I(v0[k]) + (int32_t)((I_BETA * (I(v0[k - 1]) + (int64_t)I(v0[k + 1])) + (1 << 15)) >> 16));
-                v1[k] = (uint32_t)(I(v1[k]) + (int32_t)((I_BETA * (I(v1[k - 1]) + (int64_t)I(v1[k + 1])) + (1 << 15)) >> 16));
-            }
-#pragma unroll
-            for (int k = 5; k < NR - 4; k += 2) {
-                const int64_t s0 = I(v0[k - 1]) + (int64_t)I(v0[k + 1]), s1 = I(v1[k - 1]) + (int64_t)I(v1[k + 1]);
-                int32_t t0 = I(v0[k]), t1 = I(v1[k]);
-                t0 += (int32_t)s0; t0 += (int32_t)((I_ALPHA_PRIME * s0 + (1 << 15)) >> 16);
-                t1 += (int32_t)s1; t1 += (int32_t)((I_ALPHA_PRIME * s1 + (1 << 15)) >> 16);
-                v0[k] = (uint32_t)t0; v1[k] = (uint32_t)t1;
-            }
-        }
-        /* store the rows of this thread's band that belong to the tile */
-        uint32_t *out = out_base + A.out_off;
-        const int xa = ax0 + 2 * c - g.mh;               /* output x of column v0 (v1 is xa + 1) */
-        const bool ok0 = xa >= x0 && xa < x0 + TW && xa < g.lh;
-        const bool ok1 = xa + 1 >= x0 && xa + 1 < x0 + TW && xa + 1 < g.lh;
-#pragma unroll
-        for (int k = HALO; k < NR - HALO; k++) {
-            const int y = ay0 + sy_first + k - g.mv;     /* output row */
-            if (y < y0 + grp * RPT || y >= y0 + (grp + 1) * RPT || y >= g.lv) continue;
-            uint32_t a = v0[k], b = v1[k];
-            if (TYPE == J2K_DWT97_INT && g.last) {
-                a = (uint32_t)((int32_t)((int32_t)a + 128) >> 8);
-                b = (uint32_t)((int32_t)((int32_t)b + 128) >> 8);
-            }
-            uint32_t *p = out + (size_t)y * A.out_stride + xa;
-            if (ok0 && ok1) { p[0] = a; p[1] = b; }
-            else if (ok0) p[0] = a;
-            else if (ok1) p[1] = b;
-        }
-    }
 }
 
 }  // namespace htj2k

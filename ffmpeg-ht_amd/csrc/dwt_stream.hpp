@@ -24,7 +24,7 @@
  * C16 / LL16 below, decided in htj2k_device.hip) the sub-bands the block decoder wrote are read as
  * 16-bit pairs and widened in registers: 2.5 + 1 bytes per sample at the final level.
  *
- * Boundaries: as in k_idwt_tile2, positions outside the line are fetched through the
+ * Boundaries: positions outside the line are fetched through the
  * whole-sample symmetric reflection (LineMap::idx), which is bit-identical to the reference's
  * sequential extend53/extend97 for lines of >= 2 samples; the lifting then runs on the extended
  * signal and results more than HALO positions away from the valid span are discarded.

@@ -1877,20 +1877,10 @@ __host__ __device__ inline size_t ht_vlc_lds_bytes(uint32_t max_qw)
 {
     return 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES + (size_t)((((max_qw + 3) >> 2) | 1) << 2) * 64;
 }
-/* NARROW (every block of the launch at most 32 quads = 64 columns wide): the row-above significance a context
- * needs is two bits per quad and lives in two registers, and the flush bookkeeping is fetched from the owning lane
- * with ds_bpermute.  Four waves share one copy of the decode tables, and the two stages turn over every 4 passes
- * instead of every 8 (12 + 8 dwords per lane): 26 240 bytes of LDS per 256 blocks = 6 workgroups, 24 waves per CU
- * where a wave with its own tables and 8-pass stages (16 256 bytes) allowed 10.  The bench job's 4741 waves are then
- * resident at once (18.5 per CU) instead of running as two rounds of 2560, and the SIMDs have 4-5 serial chains each
- * to interleave instead of 2.5. */
-#define HT_VLC_NARROW_WAVES 4
-#define HT_VLC_NARROW_VPITCH HT_VSTAGE_PITCH
-#define HT_VLC_NARROW_OPITCH HT_VLC_OUT_PITCH
-#define HT_VLC_LDS_NARROW (4096 + 640 + HT_VLC_NARROW_WAVES * 64 * (HT_VLC_NARROW_VPITCH + HT_VLC_NARROW_OPITCH) * 4)
-
-template <bool NARROW>
-__global__ void __launch_bounds__(NARROW ? 64 * HT_VLC_NARROW_WAVES : 64)
+/* k_ht_vlc: launches with a block wider than 64 columns (legal up to 1024 x 4); one wave per workgroup, the significance
+ * patterns of the row above in LDS byte rows.  Everything else runs k_ht_vlc2 below, which shares four waves' tables. */
+#define HT_VLC_NARROW_WAVES 4                  /* waves per workgroup of k_ht_vlc2 */
+__global__ void __launch_bounds__(64)
 k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
          const uint16_t *__restrict__ g_tables, ht_sym_t *__restrict__ qsym,
          const uint32_t *__restrict__ qoff, uint32_t max_qw,
@@ -1900,19 +1890,19 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
     uint16_t *tbl = (uint16_t *)smem;
     uint16_t *utbl = (uint16_t *)(smem + 4096);          /* HT_UVLC_ENTRIES entries */
     constexpr int CAD = 8;                               /* passes per flush of the output stage */
-    constexpr int VPITCH = NARROW ? HT_VLC_NARROW_VPITCH : HT_VSTAGE_PITCH, OPITCH = NARROW ? HT_VLC_NARROW_OPITCH : HT_VLC_OUT_PITCH;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *vstage = NARROW ? (uint32_t *)(smem + 4096 + 640) + wv * 64 * (VPITCH + OPITCH) : (uint32_t *)(smem + 4096 + 1024);
+    constexpr int VPITCH = HT_VSTAGE_PITCH, OPITCH = HT_VLC_OUT_PITCH;
+    const int lane = threadIdx.x & 63;
+    uint32_t *vstage = (uint32_t *)(smem + 4096 + 1024);
     /* output stage: the two quad symbols of a pass go to LDS; every 8 passes the wave writes the 64
      * lanes' 64-byte chunks out together, 4 lanes per chunk with 16-byte stores.  A lane storing
      * its own two dwords per pass made 128 separate line requests per pass and wave (every lane
      * writes into a different block's symbol array): that address traffic, not arithmetic, was
      * 40 % of this kernel's time. */
-    uint32_t *ostage = NARROW ? vstage + 64 * VPITCH : (uint32_t *)(smem + 4096 + 1024 + HT_VSTAGE_BYTES);
-    uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;   /* !NARROW only */
+    uint32_t *ostage = (uint32_t *)(smem + 4096 + 1024 + HT_VSTAGE_BYTES);
+    uint32_t *obase_lo = ostage + 64 * HT_VLC_OUT_PITCH, *obase_hi = obase_lo + 64, *onit = obase_hi + 64;
     /* significance patterns of the row above, one byte per quad, [lane][quad]; the pitch in
      * dwords is odd so the 64 lanes hit distinct banks */
-    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;                            /* !NARROW only */
+    uint8_t *rho_rows = smem + 4096 + 1024 + HT_VSTAGE_BYTES + HT_VLC_OUT_BYTES;
     const int pitch = (int)((((max_qw + 3) >> 2) | 1) << 2);
     const int bi = blockIdx.x * blockDim.x + threadIdx.x;
     /* the decode tables with the symbol's four fields where e_k and e_1 were: u_off | len << 1 | rho << 4 | fields << 8 */
@@ -1954,11 +1944,9 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
 #pragma unroll
     for (int o = 32; o; o >>= 1) max_it = max(max_it, __shfl_xor(max_it, o));
     const uint32_t my_lo = (uint32_t)(uintptr_t)qout, my_hi = (uint32_t)((uintptr_t)qout >> 32);
-    if (!NARROW) {
-        obase_lo[lane] = my_lo;
-        obase_hi[lane] = my_hi;
-        onit[lane] = (uint32_t)n_it;
-    }
+    obase_lo[lane] = my_lo;
+    obase_hi[lane] = my_hi;
+    onit[lane] = (uint32_t)n_it;
     __syncthreads();
 
     const uint32_t *vsrc = vlc_u + doff;
@@ -2005,9 +1993,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
             const uint32_t *src = ostage + c * OPITCH + 4 * part;
             const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
             /* the symbol array and pass count of the lane that owns chunk c */
-            const uint32_t c_lo = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_lo) : obase_lo[c];
-            const uint32_t c_hi = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, (int)my_hi) : obase_hi[c];
-            const uint32_t c_nit = NARROW ? (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c, n_it) : onit[c];
+            const uint32_t c_lo = obase_lo[c], c_hi = obase_hi[c], c_nit = onit[c];
             uint32_t *dst = (uint32_t *)(((uintptr_t)c_hi << 32) | c_lo) + (size_t)win * CAD + 4 * part;
             /* chunks of lanes that are done (or never had a block) go to a scratch line: always two
              * stores, so that the wait for the staged VLC words can be counted (vmcnt) */
@@ -2020,20 +2006,11 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
 
     int ctx_run = 0, row = 0, qx = 0;
     int rho_left = 0, ral = 0, ra_next = 0;
-    /* NARROW: bit 1 / bit 3 of the significance patterns of the row above (the two samples of a quad's lower row: all
-     * a context looks at, jpeg2000htdec.c:725-760), shifted along with the walk: bit j of A1 / A3 = quad qx + j, L1 / L3
-     * = quad qx - 1; bit q of N1 / N3 collects the current row */
-    uint32_t A1 = 0, A3 = 0, L1 = 0, L3 = 0, N1 = 0, N3 = 0;
-    /* One pass of the loop.  MAIN: every lane of the wave is inside its block and past the first quad row, and every block
-     * has an even number of quads per row -- all but the first and the last few passes of nearly every wave (the block
-     * table is sorted by size).  Then nothing is predicated: both quads of the pair exist, the contexts come from the row
-     * above, the first-row U-VLC rule (:666-712) cannot apply.  The general form runs the ragged start and end. */
-    auto pass = [&](int t, auto main_tag) {
-        constexpr bool MAIN = decltype(main_tag)::value && NARROW;
-        const bool active = MAIN || t < n_it;
-        const uint16_t *table = tbl + ((MAIN || row) ? 1024 : 0);
-        const bool row0 = !MAIN && row == 0;
-        const bool pair = MAIN || qx + 1 < qw;
+    for (int t = 0; t < max_it; t++) {
+        const bool active = t < n_it;
+        const uint16_t *table = tbl + (row ? 1024 : 0);
+        const bool row0 = row == 0;
+        const bool pair = qx + 1 < qw;
         if ((t & 1) == 0) {
             if (pend) {
                 uint32_t *r = vst + (pw & 15);
@@ -2136,20 +2113,11 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         for (int k = 0; k < 2; k++) {
             const bool en = active && (k == 0 || pair);
             const int q = qx + k;
-            int ra, rar, ctx;
-            if (NARROW) {
-                const uint32_t a1 = k ? A1 : (A1 << 1) | L1, a3 = k ? A3 : (A3 << 1) | L3;             /* bit 0: quad q-1, bit 1: q, bit 2: q+1 */
-                ra = 0; rar = 0;
-                ctx = row0 ? ctx_run
-                           : (int)((((a1 >> 1) | a3) & 1) | ((((uint32_t)rho_left >> 2) | ((uint32_t)rho_left >> 3)) & 1) << 1 |
-                                   (((a3 >> 1) | (a1 >> 2)) & 1) << 2);
-            } else {
-                ra = ra_next;
-                rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
-                ctx = row0 ? ctx_run
-                           : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
-                              ((((ra >> 3) | (rar >> 1)) & 1) << 2));
-            }
+            const int ra = ra_next;
+            const int rar = (row && en && q + 1 < qw) ? (int)myrho[q + 1] : 0;
+            const int ctx = row0 ? ctx_run
+                                 : ((((ra >> 1) | (ral >> 3)) & 1) | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) |
+                                    ((((ra >> 3) | (rar >> 1)) & 1) << 2));
             const bool mq = en && ctx == 0;
             const int msym = (int)(m & 1);
             m >>= mq ? 1 : 0; mused += mq ? 1 : 0;
@@ -2162,8 +2130,7 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
                 rho_left = rho[k];
                 ral = ra;
                 ra_next = rar;
-                if (NARROW) { N1 |= (((uint32_t)rho[k] >> 1) & 1u) << q; N3 |= (((uint32_t)rho[k] >> 3) & 1u) << q; }
-                if (!MAIN) ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);   /* first row only */
+                ctx_run = ((rho[k] | (rho[k] >> 1)) & 1) | (((rho[k] >> 2) & 1) << 1) | (((rho[k] >> 3) & 1) << 2);   /* first row only */
             }
         }
         /* U-VLC (jpeg2000htdec.c:338-388, 666-712, 828-854) for both quads, branch-free, on a
@@ -2194,35 +2161,18 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
         if (active) {
             vpos += aused + uused;
             msyms >>= mused; mcnt -= (int)mused;
-            if (!NARROW) {
-                myrho[qx] = (uint8_t)rho[0];
-                if (pair) myrho[qx + 1] = (uint8_t)rho[1];
-            }
+            myrho[qx] = (uint8_t)rho[0];
+            if (pair) myrho[qx + 1] = (uint8_t)rho[1];
         }
         ost[t & (CAD - 1)] = pk[0] | ((uint32_t)u1 << 8) | (pk[1] << 16) | ((uint32_t)u2 << 24);
         /* next quad pair of this lane's block */
         qx += 2;
-        if (NARROW) { L1 = (A1 >> 1) & 1; L3 = (A3 >> 1) & 1; A1 >>= 2; A3 >>= 2; }
         if (active && qx >= qw) {
             qx = 0; row++;
             rho_left = 0; ral = 0;
-            if (NARROW) { A1 = N1; A3 = N3; L1 = 0; L3 = 0; N1 = 0; N3 = 0; }
-            else ra_next = (int)myrho[0];                /* above quad 0 of the new row */
+            ra_next = (int)myrho[0];                     /* above quad 0 of the new row */
         }
-    };
-    /* [0, t_a): some lane is still in its first row; [t_a, t_b): the MAIN form; [t_b, max_it): some lane is done */
-    int t_a = ppr, t_b = n_it, odd = qw & 1;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        t_a = max(t_a, __shfl_xor(t_a, o));
-        t_b = min(t_b, __shfl_xor(t_b, o));
-        odd |= __shfl_xor(odd, o);
     }
-    if (!NARROW || odd || t_b < t_a) t_a = t_b = max_it;   /* no MAIN stretch */
-    int t = 0;
-    for (; t < t_a; t++) pass(t, std::false_type{});
-    for (; t < t_b; t++) pass(t, std::true_type{});
-    for (; t < max_it; t++) pass(t, std::false_type{});
     if (max_it > 0) flush((max_it - 1) / CAD);
 }
 
@@ -2247,8 +2197,10 @@ k_ht_vlc(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__rest
  *              the two u of the output word; suffix extensions (u > 32) in a branch that is taken when a lane has one.
  *   stream     a ring of 16 words per lane with its first two words mirrored behind it: the three words of a window are
  *              consecutive.
- * MAIN (see k_ht_vlc): the passes where every lane is inside its block, below the first row and all blocks have an even
- * number of quads per row run without predication.  LDS: 4 KB tables + 1 KB U-VLC + 4 waves x 64 x (18 + 9) words =
+ * MAIN: every lane of the wave is inside its block and past the first quad row, and every block has an even number of
+ * quads per row -- all but the first and the last few passes of nearly every wave (the block table is sorted by size).
+ * Then nothing is predicated: both quads of the pair exist, the contexts come from the row above, the first-row U-VLC rule
+ * (:666-712) cannot apply.  The general form of the same pass runs the ragged start and end.  LDS: 4 KB tables + 1 KB U-VLC + 4 waves x 64 x (18 + 9) words =
  * exactly a fifth of a CU's 160 KB. */
 #define HT_VLC2_VPITCH 18
 #define HT_VLC2_LDS (4096 + 1024 + HT_VLC_NARROW_WAVES * 64 * (HT_VLC2_VPITCH + HT_VLC_OUT_PITCH) * 4)

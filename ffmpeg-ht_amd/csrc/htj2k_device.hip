@@ -118,10 +118,8 @@ struct htj2k_ctx {
     uint16_t *d_tables = nullptr;      /* 2 x 1024 CxtVLC decode entries */
     J2kParser *probe_parser = nullptr;
     htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
-    int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 2 = LDS + register/DPP tile kernel,
-                                        * 3 = register-streaming kernel (dwt_stream.hpp) */
+    int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
-    int ht_vlc2 = 1;                   /* 1: launches without a block wider than 64 columns run k_ht_vlc2; 0: k_ht_vlc<true> (A/B reference) */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
     int ht_multi = 1;                  /* 1: jobs with 32-bit sub-bands whose HT blocks qualify use k_ht_decode_multi (2 or 4 blocks per wave) */
     int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
@@ -318,7 +316,6 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     const char *m = getenv("HTJ2K_IDWT");
     if (m && !strcmp(m, "generic")) c->idwt_mode = 0;
     if (m && !strcmp(m, "tile")) c->idwt_mode = 1;
-    if (m && !strcmp(m, "tile2")) c->idwt_mode = 2;
     if (m && !strcmp(m, "stream")) c->idwt_mode = 3;
     const char *l16 = getenv("HTJ2K_LL16");
     if (l16) c->ll16 = atoi(l16) ? 1 : 0;
@@ -339,7 +336,7 @@ extern "C" void htj2k_set_log(htj2k_ctx *c, htj2k_log_fn fn, void *opaque)
 extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
 {
     if (!c || !name) return HTJ2K_ERR_EINVAL;
-    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
+    if (!strcmp(name, "idwt_mode")) { c->idwt_mode = value <= 0 ? 0 : (value >= 3 ? 3 : 1); return 0; }
     if (!strcmp(name, "fuse_pack")) { c->fuse_pack = value ? 1 : 0; return 0; }
     if (!strcmp(name, "parse_threads")) { c->parse_threads = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ht_mode")) { c->ht_mode = value ? 1 : 0; return 0; }
@@ -347,7 +344,6 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "packet_threads")) { c->packet_threads = value < 1 ? 1 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "ht_vlc2")) { c->ht_vlc2 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
@@ -1313,10 +1309,6 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
         else if (TYPE == J2K_DWT53 && coef16 == 1) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
         else if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
         else hipLaunchKernelGGL((k_idwt_stream<TYPE, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
-    } else if (mode >= 2 && min_l >= 2) {
-        constexpr int TW2 = 128 - 2 * Lift<TYPE>::HALO - 2, TH2 = 64;
-        dim3 g((max_lh + TW2 - 1) / TW2, (max_lv + TH2 - 1) / TH2, count);
-        hipLaunchKernelGGL((k_idwt_tile2<TYPE>), g, dim3(256), 0, s, (const DwtTileArgs *)tab, ll, band, out);
     } else {
         dim3 g((max_lh + TILE_W - 1) / TILE_W, (max_lv + TILE_H - 1) / TILE_H, count);
         hipLaunchKernelGGL((k_idwt_tile<TYPE, TILE_W, TILE_H>), g, dim3(256), 0, s, (const DwtTileArgs *)tab, ll, band, out);
@@ -1442,14 +1434,14 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
         }
         j->coef_is16 = false;
         if (nblocks) {
-            const bool vlc_narrow = j->max_qw <= 32;               /* no block wider than 64 columns: k_ht_vlc<true> */
-            const size_t vlc_lds = vlc_narrow ? (size_t)HT_VLC_LDS_NARROW : ht_vlc_lds_bytes(j->max_qw);
+            const bool vlc_narrow = j->max_qw <= 32;               /* no block wider than 64 columns: k_ht_vlc2 */
+            const size_t vlc_lds = vlc_narrow ? (size_t)HT_VLC2_LDS : ht_vlc_lds_bytes(j->max_qw);
             /* 16-bit sub-bands only when this very call also runs the (fused, streaming) IDWT that reads them */
             j->coef_is16 = c->coef16 && j->coef16_ok && c->ht_mode == 1 && vlc_lds <= 160 * 1024 && mask == 7 &&
                            c->idwt_mode == 3 && c->fuse_pack;
             if (c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
                 if (vlc_lds > 48 * 1024)
-                    HIP_TRY(c, hipFuncSetAttribute(vlc_narrow ? (const void *)k_ht_vlc<true> : (const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds));
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
@@ -1460,13 +1452,13 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
                 const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
-                if (vlc_narrow && c->ht_vlc2)
+                if (vlc_narrow)
                     hipLaunchKernelGGL(k_ht_vlc2, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), HT_VLC2_LDS, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                        (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
                 else
-                hipLaunchKernelGGL(vlc_narrow ? k_ht_vlc<true> : k_ht_vlc<false>, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), vlc_lds, j->stream,
+                hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), vlc_lds, j->stream,
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
@@ -2163,7 +2155,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
     const size_t vlc_lds = ht_vlc_lds_bytes(tmp.lds.max_qw);
     if (e == hipSuccess && c->ht_mode == 1 && vlc_lds <= 160 * 1024) {
         if (vlc_lds > 48 * 1024)
-            e = hipFuncSetAttribute((const void *)k_ht_vlc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
+            e = hipFuncSetAttribute((const void *)k_ht_vlc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlc_lds);
         if (e == hipSuccess && (int)tmp.ext.total > 48 * 1024)
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
@@ -2173,7 +2165,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                 (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
             hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
-            hipLaunchKernelGGL(k_ht_vlc<false>, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
+            hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (ht_sym_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq / 2 + 32);
             if (!reflist.empty())

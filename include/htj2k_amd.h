@@ -232,8 +232,7 @@ int  htj2k_job_device_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_fra
  * planes of a run are final only after it (htj2k_job_device_frame waits by itself) */
 void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
 /* tuning / test knobs:
- *   "idwt_mode"   0 generic closed-form kernels, 1 LDS tile kernel, 2 LDS + DPP tile kernel,
- *                 3 register-streaming kernel (default)
+ *   "idwt_mode"   0 generic closed-form kernels, 1 LDS tile kernel, 3 register-streaming kernel (default)
  *   "fuse_pack"   1 (default): with idwt_mode 3, a run that covers both the IDWT and the pack stage
  *                 lets the final IDWT level do the inverse MCT and write the frame
  *   "ht_mode"     1 (default) k_ht_unstuff + k_ht_vlc + k_ht_decode<true>, 0 single kernel
@@ -252,7 +251,17 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *                 k_gather on the device from the parser's gather table; 0: the parser copies the code-block bytes
  *                 into the pool on the host
  *   "parse_threads"  host threads that parse the frames of a batch (0 = min(cores, 16))
- *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option */
+ *   "bitexact", "reduction_factor"   as the AVCodecContext flag / the decoder's `lowres` option
+ * Environment variables (experiments and tests; read by htj2k_open unless noted):
+ *   HTJ2K_HT=fused|split             "ht_mode" 0 | 1
+ *   HTJ2K_IDWT=generic|tile|stream   "idwt_mode" 0 | 1 | 3
+ *   HTJ2K_LL16=0|1, HTJ2K_FUSE=0|1   "ll16", "fuse_pack"
+ *   HTJ2K_MULTI_LDS=bytes            (per upload) most LDS a wave of k_ht_decode_multi may take for its blocks' MagSgn bits
+ *                                    (default 12288): above it the job decodes one block per wave
+ *   HTJ2K_STRIP=rows                 (per launch) rows per wave of the streaming IDWT kernels (default 8 or 16 by launch size)
+ *   HTJ2K_TW16 / HTJ2K_TW32 / HTJ2K_TWF=columns   (per launch) output columns per wave of the streaming IDWT for 16-bit LL
+ *                                    bands / 32-bit LL bands / the fused final level (64 .. 244; default 224 or 244 by row length)
+ *   HTJ2K_POISON=1                   fresh device buffers start as 0xA5 bytes (tools/gpu_random_configs.py) */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
 
 /* Pinned (page-locked) host memory for frame planes: a D2H copy into it runs at PCIe rate (about 5x a
