@@ -115,13 +115,62 @@ def test_random_irreversible_streams_agree_with_openjpeg_within_one_lsb(orc, see
     assert compared >= 45
 
 
-@pytest.mark.skipif(not HAVE_OPJ, reason="Pillow/OpenJPEG not importable")
+def _analysis_low(x, odd0):
+    """low-pass half of one reversible 5/3 analysis step (T.800 F.4.8) of the samples x, the first of which sits on an odd
+    (odd0) or even absolute position"""
+    n = len(x)
+    x = x.astype(np.int64)
+    if n == 1:
+        return x.copy() if not odd0 else np.zeros(0, np.int64)
+    ref = lambda i: -i if i < 0 else (2 * (n - 1) - i if i >= n else i)
+    par = 1 if odd0 else 0
+    y = x.copy()
+    for i in range(par ^ 1, n, 2):
+        y[i] = x[i] - ((x[ref(i - 1)] + x[ref(i + 1)]) >> 1)
+    z = y.copy()
+    for i in range(par, n, 2):
+        z[i] = y[i] + ((y[ref(i - 1)] + y[ref(i + 1)] + 2) >> 2)
+    return z[par::2]
+
+
+def _reduced_by_analysis(img, key, kw, red):
+    """what a decoder must return at `red` resolutions less: the LL band of `red` forward 5/3 levels of every tile (columns
+    first, then rows, as the encoder ran them), through the forward / inverse RCT where the stream has one"""
+    w, h, nc, depth = key
+    dc = 1 << (depth - 1)
+    comps = [c.astype(np.int64) - dc for c in img]
+    if kw.get("mct"):
+        r, g, b = comps[:3]
+        comps = [(r + 2 * g + b) >> 2, b - g, r - g] + comps[3:]
+    tw, th = kw.get("tile", (w, h))
+    up = lambda v: (v + (1 << red) - 1) >> red
+    out = [np.zeros((up(h), up(w)), np.int64) for _ in comps]
+    for ty in range(0, h, th):
+        for tx in range(0, w, tw):
+            for ci, c in enumerate(comps):
+                a, x0, y0 = c[ty:ty + th, tx:tx + tw], tx, ty
+                for _ in range(red):
+                    a = np.stack([_analysis_low(col, y0 & 1) for col in a.T]).T if a.size else a
+                    a = np.stack([_analysis_low(row, x0 & 1) for row in a]) if a.size else a
+                    x0, y0 = (x0 + 1) >> 1, (y0 + 1) >> 1
+                if a.size:
+                    out[ci][up(ty):up(ty) + a.shape[0], up(tx):up(tx) + a.shape[1]] = a
+    if kw.get("mct"):
+        y, cb, cr = out[:3]
+        g = y - ((cb + cr) >> 2)
+        out = [cr + g, g, cb + g] + out[3:]
+    ref = np.clip(np.stack(out, -1) + dc, 0, (1 << depth) - 1)
+    return ref << (16 - depth) if depth > 8 else ref
+
+
 @pytest.mark.parametrize("seed", [21, 22])
-def test_random_reversible_streams_at_reduced_resolution_agree_with_openjpeg(orc, seed):
-    """`lowres` (jpeg2000dec.c:2913-2917, reduction_factor) against OpenJPEG's reduce: the lower resolution of a reversible
-    stream is an exact integer reconstruction too"""
+def test_random_reversible_streams_at_reduced_resolution(orc, seed):
+    """`lowres` (jpeg2000dec.c:2913-2917, reduction_factor): the lower resolution of a reversible stream is an exact integer
+    reconstruction too -- the LL band the encoder's analysis left at that level.  Checked against that band computed
+    independently here (cleanup-only streams), and against OpenJPEG's `reduce` where Pillow's build accepts the size; where
+    the two decoders differ the analysis says who is right"""
     rng = np.random.default_rng(seed)
-    compared = 0
+    by_analysis = by_opj = 0
     for it in range(90):
         key, kw, img = _draw(rng, 100 * seed + it)
         kw.pop("offset", None)
@@ -134,6 +183,13 @@ def test_random_reversible_streams_at_reduced_resolution_agree_with_openjpeg(orc
             continue
         info, planes, _ = orc.decode(data, reduction_factor=red)
         assert orc.block_errors() == 0, (key, kw, red)
+        ref = None
+        if "passes" not in kw:                                             # (streams with refinement passes: OpenJPEG only)
+            ref = _reduced_by_analysis(img, key, kw, red)
+            assert np.array_equal(planes[0].reshape(ref.shape).astype(np.int64), ref), (key, kw, red)
+            by_analysis += 1
+        if not HAVE_OPJ:
+            continue
         im = Image.open(io.BytesIO(data))
         im.reduce = red
         try:
@@ -141,7 +197,12 @@ def test_random_reversible_streams_at_reduced_resolution_agree_with_openjpeg(orc
         except (OSError, ValueError):
             continue                                                       # Pillow's OpenJPEG gives up on some reduced sizes
         a = np.array(im)
-        got = planes[0].reshape(a.shape)
-        assert np.array_equal(got.astype(np.int64), a.astype(np.int64)), (key, kw, red)
-        compared += 1
-    assert compared >= 25, compared
+        diff = int(np.abs(planes[0].reshape(a.shape).astype(np.int64) - a.astype(np.int64)).max())
+        same = diff == 0
+        # ref is not None: the oracle equals the analysis band, OpenJPEG is the one that is off.  passes == 2 (cleanup +
+        # SigProp, no MagRef: a truncated, lossy stream): a line of ONE sample at an odd position is halved with an
+        # arithmetic shift by the reference (jpeg2000dwt.c:313-317, `(int)p[1] >> 1`) and with a division by OpenJPEG --
+        # the same for the even values a complete stream holds there, one apart for negative odd ones
+        assert same or ref is not None or (kw.get("passes") == 2 and diff <= 2), (key, kw, red, diff)
+        by_opj += same
+    assert by_analysis >= 20 and (by_opj >= 20 or not HAVE_OPJ), (by_analysis, by_opj)
