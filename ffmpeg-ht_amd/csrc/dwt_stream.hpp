@@ -139,15 +139,19 @@ template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 =
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by,
-                 int *__restrict__ ovf = nullptr, int ovf_bits = 16)
+                 int *__restrict__ ovf = nullptr, int ovf_bits = 16, int y0_rows = -1, int dir_in = 0, int ll_row0 = 0, int out_row0 = 0)
 {
+    /* ll_row0 / out_row0 (FAST 16-bit paths only): the LL input / the output is a window whose first row is row ll_row0 /
+     * out_row0 of the band (k_idwt_stream_ll16_x3's LDS windows) */
     using O = LiftOps<TYPE>;
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
     const DwtLevel g = A[0].g;
-    const int x0 = bx * tw, y0 = by * th;
+    /* the strip: columns [bx tw, bx tw + tw), rows [by th, by th + th) -- or, for callers that cut a level their own way
+     * (k_idwt_stream_ll16_x3), rows [y0_rows, y0_rows + th) walked in direction dir_in */
+    const int x0 = bx * tw, y0 = y0_rows >= 0 ? y0_rows : by * th;
     if (x0 >= g.lh || y0 >= g.lv) return;
     const LineMap LX(g.mh, g.lh), LY(g.mv, g.lv);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;                   /* (k_idwt_stream_ll16_x3 runs four waves per workgroup) */
 
     /* ---- columns of this lane ---- */
     const int ax0 = (g.mh + x0 - 4) & ~1;                 /* even; lane 1 starts at or one before the strip */
@@ -182,7 +186,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
      * vertically adjacent strips -- which start together: consecutive strip numbers on one XCD -- then
      * read the HALO rows they share at the same moment (both at their start, or both at their end)
      * and the second reader hits in L2 instead of fetching them again. */
-    const int dir = (by & 1) ? -1 : 1;
+    const int dir = dir_in ? dir_in : ((by & 1) ? -1 : 1);
     const int s_first = dir > 0 ? (a_first - HALO) & ~1 : (a_last + HALO + 1) & ~1;
     const int s_last = dir > 0 ? (a_last + DELAY + 1) & ~1 : (a_first - DELAY) & ~1;
 
@@ -212,7 +216,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 Hr[c][0] = *(const uint32_t *)(brow1 + col[0]);
                 Hr[c][1] = *(const uint32_t *)(brow1 + col[1]);
                 if (LL16) {
-                    const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)iy[0] * A[c].ll_stride;
+                    const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)(iy[0] - ll_row0) * A[c].ll_stride;
                     Lr[c][0] = *(const uint32_t *)(lrow + col[0]);
                 } else {
                     const uint2 le = *(const uint2 *)(llp[c] + (size_t)iy[0] * A[c].ll_stride + col[0]);
@@ -300,7 +304,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
             if (!FUSED && OUTK == 16) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    uint16_t *p = (uint16_t *)out_base + A[c].out_off + (size_t)y * A[c].out_stride + xa;
+                    uint16_t *p = (uint16_t *)out_base + A[c].out_off + (size_t)(y - out_row0) * A[c].out_stride + xa;
                     /* v + 0x8000 < 0x10000 exactly for v in [-32768, 32767] (ovf_bits = 16; fewer bits: the tests' way to
                      * make ordinary frames take the overflow path) */
                     const uint32_t hb = 1u << (ovf_bits - 1);
@@ -636,6 +640,78 @@ k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restr
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
     idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
+}
+
+/* ================================================================== three levels in one launch
+ * The first three levels of a 4K plane are 240 x 135, 480 x 270 and 960 x 540 samples: launches of a few thousand waves that
+ * end before the chip is full (1.3 / 2.9 / 4.0 TB/s where the big levels reach 4.8), and each writes an LL band only for the
+ * next to read it back.  Here one workgroup (4 waves) reconstructs a band of TH rows of the THIRD level's output of one plane:
+ * the rows of the first level it needs (through two levels of lifting: TH / 4 + a few) into LDS, from those the rows of the
+ * second level (TH / 2 + a few) into LDS, from those its own rows to memory.  The two intermediate LL bands never leave the
+ * CU; neighbouring workgroups recompute the few rows they share.  Every level is idwt_stream_impl as it stands -- the same
+ * code, the same arithmetic, the same 16-bit range check (`ovf`) on what a level stores -- with its LL input and / or its
+ * output pointing into LDS (generic pointers: the loads and stores become FLAT ones).  For jobs with 16-bit sub-bands and LL
+ * bands whose planes all start at the origin; everything else runs the levels one launch each. */
+struct X3Rows { int lo0, n0, lo1, n1; };          /* first-level rows [lo0, lo0 + n0) and second-level rows [lo1, lo1 + n1) a band needs */
+__host__ __device__ inline X3Rows x3_rows(int r0, int r1, int lv0, int lv1)
+{
+    /* a strip of rows [a, b) of a level reads its LL input at the even absolute rows from (a - 2) & ~1 to (b + 1) & ~1,
+     * reflected into the level: LL rows (a - 2) >> 1 .. (b + 1) >> 1, clamped */
+    X3Rows R;
+    R.lo1 = (r0 - 2) >> 1; if (R.lo1 < 0) R.lo1 = 0;
+    int hi1 = (r1 + 1) >> 1; if (hi1 > lv1 - 1) hi1 = lv1 - 1;
+    R.n1 = hi1 - R.lo1 + 1;
+    R.lo0 = (R.lo1 - 2) >> 1; if (R.lo0 < 0) R.lo0 = 0;
+    int hi0 = (hi1 + 2) >> 1; if (hi0 > lv0 - 1) hi0 = lv0 - 1;
+    R.n0 = hi0 - R.lo0 + 1;
+    return R;
+}
+/* rows of LDS the two windows take for bands of `th` third-level rows */
+__host__ __device__ inline int x3_win0_rows(int th) { return th / 4 + 6; }
+__host__ __device__ inline int x3_win1_rows(int th) { return th / 2 + 5; }
+
+__global__ void __launch_bounds__(256)
+k_idwt_stream_ll16_x3(const DwtTileArgs *__restrict__ args0, const DwtTileArgs *__restrict__ args1, const DwtTileArgs *__restrict__ args2,
+                      const uint32_t *__restrict__ coef, uint32_t *__restrict__ out_base, int th, int nbands, int nplanes, int max_lh0, int max_lh1,
+                      int *__restrict__ ovf, int ovf_bits)
+{
+    extern __shared__ __align__(16) uint16_t x3_lds[];
+    /* as stream_strip(): every XCD gets a contiguous run of (plane, band) pairs, so that bands which share rows share an L2 */
+    const int total = nplanes * nbands, per_xcd = (total + 7) / 8;
+    const int sidx = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (sidx >= total) return;                               /* (whole workgroup) */
+    const int plane = sidx / nbands, band = sidx % nbands;
+    const int wv = threadIdx.x >> 6;
+    DwtTileArgs A0[1] = { args0[plane] }, A1[1] = { args1[plane] }, A2[1] = { args2[plane] };
+    const int r0 = band * th, r1 = min(r0 + th, A2[0].g.lv);
+    if (r0 >= A2[0].g.lv) return;                           /* (whole workgroup) */
+    const X3Rows R = x3_rows(r0, r1, A0[0].g.lv, A1[0].g.lv);
+    uint16_t *w0 = x3_lds, *w1 = x3_lds + (size_t)x3_win0_rows(th) * max_lh0;
+    /* the windows as planes whose first row is row lo0 / lo1 of their band: offsets 0, stride = the level's width */
+    uint32_t *out0 = (uint32_t *)w0, *out1 = (uint32_t *)w1;
+    A0[0].out_off = 0; A0[0].out_stride = A0[0].g.lh;
+    A1[0].ll_off = 0;  A1[0].ll_stride = A0[0].g.lh;
+    A1[0].out_off = 0; A1[0].out_stride = A1[0].g.lh;
+    A2[0].ll_off = 0;  A2[0].ll_stride = A1[0].g.lh;
+    constexpr int TW = STREAM_TW;
+    auto level = [&](const DwtTileArgs (&A)[1], const uint32_t *ll, uint32_t *out, int lo, int n, int ll_row0, int out_row0) {
+        constexpr bool LL16 = true;                          /* every LL input here is 16-bit: the coefficient buffer's, or a window */
+        const int ncol = (A[0].g.lh + TW - 1) / TW;
+        int nrow = max(1, 4 / ncol);                         /* row parts, so that the four waves all have a strip */
+        int part = ((n + nrow - 1) / nrow + 1) & ~1;         /* an even number of rows each */
+        if (part < 2) part = 2;
+        nrow = (n + part - 1) / part;
+        for (int i = wv; i < ncol * nrow; i += 4) {
+            const int bx = i % ncol, pr = i / ncol;
+            const int y0 = lo + pr * part, rows = min(part, lo + n - y0);
+            idwt_stream_impl<J2K_DWT53, 1, false, true, true, LL16, 16>(A, ll, coef, out, nullptr, 0, rows, TW, bx, 0, ovf, ovf_bits, y0, 1, ll_row0, out_row0);
+        }
+    };
+    level(A0, coef, out0, R.lo0, R.n0, 0, R.lo0);
+    __syncthreads();
+    level(A1, (const uint32_t *)out0, out1, R.lo1, R.n1, R.lo0, R.lo1);
+    __syncthreads();
+    level(A2, (const uint32_t *)out1, out_base, r0, r1 - r0, R.lo1, 0);
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */

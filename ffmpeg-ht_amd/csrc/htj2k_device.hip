@@ -120,6 +120,7 @@ struct htj2k_ctx {
     htj2k_job *own_job = nullptr;      /* used by htj2k_decode */
     int idwt_mode = 3;                 /* 0 = generic two-pass kernels, 1 = LDS tile kernel, 3 = register-streaming kernel (dwt_stream.hpp) */
     int fuse_pack = 1;                 /* idwt_mode 3, IDWT and pack stages run in one call: the final level writes the frame */
+    int idwt_x3 = 1;                   /* 1: jobs with 16-bit LL bands run the first three 5/3 levels as one launch (k_idwt_stream_ll16_x3) */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
     int ht_multi = 1;                  /* 1: jobs with 32-bit sub-bands whose HT blocks qualify use k_ht_decode_multi (2 or 4 blocks per wave) */
     int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
@@ -223,6 +224,11 @@ struct htj2k_job {
     std::vector<uint8_t> tile_fusable;         /* per PackTile */
     std::vector<uint8_t> plane_fused;          /* per tilecomp: the last IDWT run never wrote its final plane */
     bool any_fusable = false;
+    /* k_idwt_stream_ll16_x3: the first three 5/3 levels of every plane in one launch (jobs with 16-bit LL bands) */
+    bool x3_ok = false;
+    size_t x3_tab[3] = { 0, 0, 0 };            /* the three levels' DwtTileArgs tables in d_desc (same planes, same order) */
+    int x3_count = 0, x3_lh[3] = { 0, 0, 0 }, x3_lv2 = 0;
+    double x3_alg = 0, x3_hbm = 0;
     bool fused_last = false;                   /* the last run used launches_fused */
     size_t pack_off = 0; int npack = 0; int pack_maxw = 0, pack_maxh = 0;
     HtLds lds;
@@ -344,6 +350,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "packet_threads")) { c->packet_threads = value < 1 ? 1 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "idwt_x3")) { c->idwt_x3 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
@@ -1006,6 +1013,34 @@ static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
             }
         for (int t = 0; t < ntc; t++) j->plane_fused[t] = in_group[t];
     }
+    /* levels 0-2 of the reversible planes as one launch: the three plain launches must list the same planes (none of them has
+     * its final level there), every level of fast geometry, every plane at the origin of its level */
+    j->x3_ok = false;
+    {
+        const LevelLaunch *L3[3] = { nullptr, nullptr, nullptr };
+        for (const LevelLaunch &L : j->launches_fused)
+            if (L.type == J2K_DWT53 && L.nc == 0 && L.level < 3) L3[L.level] = &L;
+        if (L3[0] && L3[1] && L3[2] && L3[0]->count == L3[1]->count && L3[1]->count == L3[2]->count) {
+            bool ok = true;
+            double alg = 0, hbm = 0;
+            for (int k = 0; k < 3 && ok; k++) {
+                const DwtTileArgs *A = (const DwtTileArgs *)(j->h_desc.data() + L3[k]->table_off);
+                for (int i = 0; i < L3[k]->count && ok; i++) {
+                    ok = stream_fast_geom(A[i].g) && A[i].g.mh == 0 && A[i].g.mv == 0;
+                    const double n = (double)A[i].g.lh * A[i].g.lv;
+                    alg += 8.0 * n;
+                    hbm += 2.0 * n * (k == 0 ? 1.0 : 0.75) + (k == 2 ? 2.0 * n : 0.0);   /* 16-bit: the sub-bands in, the third level out */
+                }
+                j->x3_tab[k] = L3[k]->table_off;
+                j->x3_lh[k] = L3[k]->max_lh;
+            }
+            /* (the planes of a launch are listed in tile-component order by every level: same index, same plane) */
+            j->x3_ok = ok;
+            j->x3_count = L3[0]->count;
+            j->x3_lv2 = L3[2]->max_lv;
+            j->x3_alg = alg; j->x3_hbm = hbm;
+        }
+    }
     (void)c;
     return 0;
 }
@@ -1373,7 +1408,29 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
     j->lev_bytes.clear();
     j->lev_hbm.clear();
     const std::vector<LevelLaunch> &LL = fuse ? j->launches_fused : use_tile ? j->launches_tile : j->launches_generic;
+    bool x3 = false;
+    if (fuse && j->ll16_run && j->x3_ok && c->idwt_x3) {
+        const int th = getenv("HTJ2K_X3_TH") ? std::max(8, atoi(getenv("HTJ2K_X3_TH")) & ~3) : 36;
+        const size_t lds = ((size_t)x3_win0_rows(th) * j->x3_lh[0] + (size_t)x3_win1_rows(th) * j->x3_lh[1]) * sizeof(uint16_t);
+        if (lds <= 64 * 1024) {
+            x3 = true;
+            const int nbands = (j->x3_lv2 + th - 1) / th, total = nbands * j->x3_count;
+            hipEvent_t e0 = lev_event(j);
+            if (e0) (void)hipEventRecord(e0, j->stream);
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_idwt_stream_ll16_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_idwt_stream_ll16_x3, dim3(8 * ((total + 7) / 8)), dim3(256), lds, j->stream,
+                               (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[0]), (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[1]),
+                               (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[2]), (const uint32_t *)j->d_coef.p, buf_ptr(j, 1),
+                               th, nbands, j->x3_count, j->x3_lh[0], j->x3_lh[1], (int *)j->d_status.p + j->blocks.size(), c->ll16_test_bits);
+            hipEvent_t e1 = lev_event(j);
+            if (e1) (void)hipEventRecord(e1, j->stream);
+            j->lev_bytes.push_back(j->x3_alg);
+            j->lev_hbm.push_back(j->x3_hbm);
+        }
+    }
     for (const LevelLaunch &L : LL) {
+        if (x3 && L.type == J2K_DWT53 && L.nc == 0 && L.level < 3) continue;     /* done by k_idwt_stream_ll16_x3 */
         hipEvent_t e0 = lev_event(j);
         if (e0) (void)hipEventRecord(e0, j->stream);
         if (L.nc) {

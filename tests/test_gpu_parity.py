@@ -546,6 +546,61 @@ def test_ll16_jobs_match_int32_ll_bands_and_the_oracle(dec, orc):
         dec.set_int("ll16", 1)
 
 
+def test_first_three_idwt_levels_in_one_launch(dec, orc):
+    """knob "idwt_x3" (default on): jobs with 16-bit LL bands run the first three 5/3 levels of every plane as ONE launch
+    whose intermediate LL bands stay in LDS (k_idwt_stream_ll16_x3).  Same frames as with one launch per level, as the
+    oracle and as the source -- over heights that leave odd row counts and short last bands at every level, band heights
+    from 8 rows up (HTJ2K_X3_TH), several frames per job, mixed plane sizes (4:2:0), and with the overflow check of the
+    16-bit LL bands firing (ll16_test_bits)"""
+    cases = [(256, 192, 3, 4, {}), (512, 256, 3, 5, {}), (1920, 1080, 3, 5, {}), (1024, 542, 1, 5, {}), (256, 46, 1, 4, {}),
+             (1024, 70, 3, 5, dict(cb=(5, 5))), (512, 258, 1, 4, {})]
+    try:
+        for (w, h, nc, nl, kw) in cases:
+            img = vecgen.synth_image(w, h, nc, seed=w + h + nl, noise=10)
+            data = vecgen.encode(img, mct=1 if nc == 3 else 0, nlevels=nl, **kw)
+            info_o, planes_o, _ = orc.decode(data)
+            got = {}
+            for x3, th in ((0, 36), (1, 36), (1, 8), (1, 20)):
+                dec.set_int("idwt_x3", x3)
+                os.environ["HTJ2K_X3_TH"] = str(th)
+                job = dec.job().parse_batch([data, data, data]).upload().run().wait()
+                assert job.coef16() and job.ll16() == 1 and job.block_errors() == 0, (w, h, x3)
+                n_launch = len(job.idwt_launches())
+                assert n_launch == (nl if x3 == 0 else nl - 2), (w, h, nl, x3, n_launch)     # levels 0-2 as one launch
+                got[(x3, th)] = [job.download_frame(f)[1] for f in range(3)]
+                job.free()
+            for k, frames in got.items():
+                for f in range(3):
+                    assert all(np.array_equal(a, d) for a, d in zip(frames[f], planes_o)), (w, h, k, f)
+            if nc == 3:
+                assert np.array_equal(got[(1, 36)][0][0].reshape(h, w, 3), np.stack(img, -1))
+        # 4:2:0: planes of two sizes in one launch
+        img = vecgen.synth_image(1024, 512, 3, seed=12, dx=[1, 2, 2], dy=[1, 2, 2])
+        data = vecgen.encode(img, nlevels=4, dx=[1, 2, 2], dy=[1, 2, 2], width=1024, height=512)
+        info_o, planes_o, _ = orc.decode(data)
+        for x3 in (0, 1):
+            dec.set_int("idwt_x3", x3)
+            job = dec.job().parse_batch([data, data]).upload().run().wait()
+            assert job.ll16() == 1
+            for f in range(2):
+                assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(f)[1], planes_o)), ("420", x3, f)
+            job.free()
+        # the range check of what a level stores also guards the bands that stay in LDS
+        dec.set_int("idwt_x3", 1)
+        dec.set_int("ll16_test_bits", 6)
+        img = vecgen.synth_image(512, 256, 3, seed=5, noise=10)
+        data = vecgen.encode(img, mct=1, nlevels=5)
+        info_o, planes_o, _ = orc.decode(data)
+        job = dec.job().parse_batch([data]).upload().run().wait()
+        assert job.ll16() == 2                                           # overflowed: the transform ran again with int32 LL bands
+        assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(0)[1], planes_o))
+        job.free()
+    finally:
+        dec.set_int("idwt_x3", 1)
+        dec.set_int("ll16_test_bits", 16)
+        os.environ.pop("HTJ2K_X3_TH", None)
+
+
 def test_ll16_overflow_runs_the_transform_again(dec, orc):
     """Nothing bounds the LL bands of crafted or corrupt coefficient data, so the level kernels flag a sample that does
     not fit and the job repeats the IDWT with int32 LL bands before it hands out frames.  A stream produced by a forward
