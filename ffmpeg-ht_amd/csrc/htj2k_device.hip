@@ -1410,7 +1410,7 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
     const std::vector<LevelLaunch> &LL = fuse ? j->launches_fused : use_tile ? j->launches_tile : j->launches_generic;
     bool x3 = false;
     if (fuse && j->ll16_run && j->x3_ok && c->idwt_x3) {
-        const int th = getenv("HTJ2K_X3_TH") ? std::max(8, atoi(getenv("HTJ2K_X3_TH")) & ~3) : 36;
+        const int th = getenv("HTJ2K_X3_TH") ? std::max(8, atoi(getenv("HTJ2K_X3_TH")) & ~3) : 24;   /* C2: 91 us at 24 rows, 93 at 36, 97 at 16 or 48, 104 at 68 (three launches: 123) */
         const size_t lds = ((size_t)x3_win0_rows(th) * j->x3_lh[0] + (size_t)x3_win1_rows(th) * j->x3_lh[1]) * sizeof(uint16_t);
         if (lds <= 64 * 1024) {
             x3 = true;

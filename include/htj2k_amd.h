@@ -245,6 +245,8 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *                 block per wavefront, a lane per sample column
  *   "coef16"      1 (default): jobs that qualify keep the sub-bands as 16-bit samples (htj2k_job_coef16)
  *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
+ *   "idwt_x3"     1 (default): jobs with 16-bit LL bands run the first three 5/3 levels of every plane as one launch, the LL
+ *                 bands in between in LDS (k_idwt_stream_ll16_x3); 0: one launch per level
  *   "ll16"        1 (default): such jobs also hold the LL bands between the IDWT levels as 16-bit samples, with a check
  *                 on the device and a second run with int32 LL bands should one not fit (htj2k_job_ll16)
  *   "device_gather"  1 (default): packets are uploaded as they are and the byte pool of the job is put together by
@@ -261,6 +263,7 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   HTJ2K_STRIP=rows                 (per launch) rows per wave of the streaming IDWT kernels (default 8 or 16 by launch size)
  *   HTJ2K_TW16 / HTJ2K_TW32 / HTJ2K_TWF=columns   (per launch) output columns per wave of the streaming IDWT for 16-bit LL
  *                                    bands / 32-bit LL bands / the fused final level (64 .. 244; default 224 or 244 by row length)
+ *   HTJ2K_X3_TH=rows                 (per launch) rows of the third level one workgroup of k_idwt_stream_ll16_x3 reconstructs (default 24)
  *   HTJ2K_POISON=1                   fresh device buffers start as 0xA5 bytes (tools/gpu_random_configs.py) */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);
 
