@@ -63,6 +63,11 @@ struct HtLds {
  * MSB), bits 8-15 the U-VLC value u (at most 2 + 5 + 31 + 4 * 15).  (Until round 2 a dword: rho | e_k << 4 | e_1 << 8 |
  * u << 16 -- the symbol array was 1.24 GB written and read again per 48 4K frames.) */
 typedef uint16_t ht_sym_t;
+/* words of the un-stuffed arrays of one block: [0, ht_nsw) VLC resp. MEL, [ht_nsw, ht_nsw + ht_nsp) SigProp
+ * resp. MagRef (blocks with refinement passes); both fit the block's byte region (J2K_BLOCK_PAD) */
+__host__ __device__ inline uint32_t ht_nsw(uint32_t Scup) { return (Scup * 8 + 31) / 32 + 2; }
+__host__ __device__ inline uint32_t ht_nsp(uint32_t Lref) { return (Lref * 8 + 31) / 32 + 3; }
+
 __host__ __device__ inline uint32_t ht_sym_pack_fields(uint32_t rho, uint32_t ek, uint32_t e1)
 {
     uint32_t pk = 0;
@@ -879,28 +884,74 @@ __device__ __forceinline__ uint32_t seg_last(uint32_t v)             /* the valu
 /* REFINE: some blocks of the job carry SigProp / MagRef passes; their decisions come from k_ht_refine as three 64-bit
  * masks per sample row (newly significant, its sign, MagRef bit) and are applied to mu before the dequantisation, as
  * in ht_magsgn_rows_narrow (jpeg2000htdec.c:1309-1315, :1066-1100, :1160-1185) */
+/* LDS of a REFINE launch behind the MagSgn bit arrays, per block: the un-stuffed MagRef bits (mr_words words), the SigProp
+ * masks of k_ht_refine (newly significant, sign: 2 masks of MW words per sample row, rg_rows rows); then once per wave two
+ * 256-byte tables: symbol fields -> the quad's four significance bits, and (4 significance bits, 4 stream bits) -> the
+ * stream bits dealt out to the significant positions */
+__host__ __device__ inline size_t ht_multi_refine_lds(int nb, uint32_t mr_words, uint32_t rg_rows)
+{
+    const uint32_t mw = nb == 4 ? 1u : 2u;
+    return (size_t)nb * (mr_words + 2 * mw * rg_rows) * 4 + 512;
+}
+
 template <int NB, int TRANSFORM, bool REFINE>
 __global__ void __launch_bounds__(64)
 k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
                   uint32_t *__restrict__ coef, int *__restrict__ status, uint32_t ms_words,
                   const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff, uint32_t *__restrict__ sink,
-                  const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff)
+                  const uint64_t *__restrict__ refbits, const uint32_t *__restrict__ roff,
+                  const uint32_t *__restrict__ mel_u, uint32_t mr_words, uint32_t rg_rows)
 {
     constexpr int LPB = 64 / NB, PF = 8 / NB;                /* lanes per block; 512-byte pieces of a block's bytes requested up front */
+    constexpr int MW = NB == 4 ? 1 : 2;                      /* words of a SigProp row mask: blocks of at most 32 / 64 columns */
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t *ms_all = (uint32_t *)smem;                     /* [NB][ms_words + 4] */
     const int lane = threadIdx.x, seg = lane / LPB, q = lane % LPB;
     const uint32_t mspitch = ms_words + 4;
+    uint32_t *mr_all = ms_all + NB * mspitch;                /* REFINE: [NB][mr_words] */
+    uint32_t *rg_all = mr_all + NB * mr_words;               /* REFINE: [NB][rg_rows][R, G][MW] */
+    uint8_t *lut_rho = (uint8_t *)(rg_all + NB * 2 * MW * rg_rows), *lut_dep = lut_rho + 256;
     bool ok_s[NB];
-    uint32_t lastwi_s[NB], Pcup_s[NB];
+    uint32_t lastwi_s[NB], Pcup_s[NB], Scup_s[NB];
     const uint32_t *Dw_s[NB];
     uint2 pv[NB][PF];
+
+    /* ---- this lane's quad symbols of the first 32 quad rows, requested before anything else (see k_ht_decode_pair) ---- */
+    const int bi = min(NB * (int)blockIdx.x + seg, nblocks - 1);
+    uint32_t sy[16];
+    {
+        const uint32_t wh = *(const uint32_t *)&blocks[bi].w;      /* w | h << 16 */
+        const int w_l = (int)(wh & 0xFFFFu), qw_l = (w_l + 1) >> 1;
+        const uint32_t qwp_l = ht_qsym_pitch((uint32_t)w_l);
+        const ht_sym_t *qp0 = qsym + qoff[bi] + (q < qw_l ? q : 0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t a = qp0[0], c = qp0[qwp_l];
+            sy[k] = a | (c << 16);
+            qp0 += 2 * qwp_l;
+        }
+        if (q >= qw_l) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) sy[k] = 0;
+        }
+    }
+    if (REFINE) {
+        /* field byte of a symbol -> rho of the quad; (rho-like mask, four stream bits) -> the bits at the mask's set positions */
+        for (int i = lane; i < 256; i += 64) {
+            const uint32_t x = ((uint32_t)i | ((uint32_t)i >> 1)) & 0x55u;
+            lut_rho[i] = (uint8_t)((x & 1u) | ((x >> 1) & 2u) | ((x >> 2) & 4u) | ((x >> 3) & 8u));
+            uint32_t m = (uint32_t)i >> 4, bts = (uint32_t)i & 15u, d = 0;
+            for (int n = 0; n < 4; n++)
+                if ((m >> n) & 1u) { d |= (bts & 1u) << n; bts >>= 1; }
+            lut_dep[i] = (uint8_t)d;
+        }
+    }
 
     /* ---- per block, whole wave: checks, zero-fill of blocks without passes; the MagSgn bytes of all blocks are
      * requested before any is worked on ---- */
 #pragma unroll
     for (int hb = 0; hb < NB; hb++) {
-        ok_s[hb] = false; lastwi_s[hb] = 0; Pcup_s[hb] = 0; Dw_s[hb] = nullptr;
+        ok_s[hb] = false; lastwi_s[hb] = 0; Pcup_s[hb] = 0; Scup_s[hb] = 0; Dw_s[hb] = nullptr;
 #pragma unroll
         for (int jx = 0; jx < PF; jx++) pv[hb][jx] = make_uint2(0u, 0u);
         const int bidx = NB * (int)blockIdx.x + hb;
@@ -931,6 +982,7 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         }
         if (!err && maxbp >= 32) err = HT_ERR_INVALID;
         if (!err && ((Pcup * 8 + 31) / 32 + 3 > ms_words || ((b.w + 1) >> 1) > LPB)) err = HT_ERR_INVALID;
+        if (!err && REFINE && b.npasses - num_plhd > 1 && (b.h > rg_rows || (b.lref && ht_nsp(b.lref) > mr_words))) err = HT_ERR_INVALID;   /* (host-sized) */
         if (err) {
             ht_zero_window(dst, b.w, b.h, b.stride, lane);
             if (lane == 0) status[bidx] = err;
@@ -938,6 +990,7 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         }
         ok_s[hb] = true;
         Pcup_s[hb] = Pcup;
+        Scup_s[hb] = Scup;
     }
     bool any_ok = false;
 #pragma unroll
@@ -965,7 +1018,6 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
     if (!any_ok) return;
 
     /* ---- all blocks in lockstep: this lane's block ---- */
-    const int bi = min(NB * (int)blockIdx.x + seg, nblocks - 1);
     const J2kBlock b = blocks[bi];
     bool ok = false;
     uint32_t last_wi = 0;
@@ -988,25 +1040,49 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
     const ht_sym_t *qp = qsym + qoff[bi] + q;
     uint32_t *prow = coef + b.plane_off + 2 * q;             /* this quad's two columns, row 2 * row */
     const int z_blk = b.npasses - num_plhd;
-    const uint64_t *rb = (REFINE && ok && z_blk > 1) ? refbits + roff[bi] : nullptr;
+    const bool refined = REFINE && ok && z_blk > 1;          /* this lane's block carries SigProp (and with z_blk > 2 MagRef) decisions */
+    uint32_t *mr = mr_all + seg * mr_words, *rg = rg_all + seg * 2 * MW * rg_rows;
+    if (REFINE) {
+        /* the blocks' MagRef bits (k_ht_unstuff: zero past either end) and SigProp masks (k_ht_refine) into LDS, every block by
+         * its own lanes, all loads of the wave in flight together: the row loop then holds no load whose wait would also be
+         * a wait for the stores in front of it */
+        uint32_t Scup = 0;
+#pragma unroll
+        for (int hb = 0; hb < NB; hb++)
+            if (seg == hb) Scup = Scup_s[hb];
+        const uint32_t nsp = (refined && b.lref) ? ht_nsp(b.lref) : 0u;
+        const uint32_t *src = mel_u + (b.data_off >> 2) + ht_nsw(Scup);
+        for (uint32_t i = q; i < mr_words; i += LPB) mr[i] = i < nsp ? src[i] : 0u;
+        const uint32_t *rsrc = (const uint32_t *)(refbits + roff[bi]);
+        const uint32_t nrg = refined ? 2u * MW * (uint32_t)h : 0u;
+        for (uint32_t i = q; i < nrg; i += LPB) {
+            const uint32_t y = i / (2 * MW), k = (i / MW) & 1u, wd = i % MW;
+            rg[i] = rsrc[((size_t)(3 * y + k) * HT_REF_STRIDE) * 2 + wd];
+        }
+        __syncthreads();
+    }
     int rows = 0;
 #pragma unroll
     for (int hb = 0; hb < NB; hb++) rows = max(rows, __builtin_amdgcn_readlane(qh, hb * LPB));
     /* odd widths: the last quad of a row has one column -- such waves store dwords, the others pairs */
     const bool pairs = __ballot(act && !c2) == 0;
-    uint32_t qi_next = (act && qh > 0) ? *qp : 0u;
-    uint32_t E1p = 0, E3p = 0, ms_pos = 0;
+    const bool pre = rows <= 32;                             /* (REFINE launches: always, the host admits blocks of at most 64 rows) */
+    uint32_t qi_next = (!pre && act && qh > 0) ? *qp : 0u;
+    uint32_t E1p = 0, E3p = 0, ms_pos = 0, mr_pos = 0, dB = 0;
     int err = 0;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
-    for (int row = 0; row < rows; row++) {
+    /* one quad row; `qi` the lane's symbol, `qn` the symbol of the row below (REFINE: the MagRef bits of a stripe of four
+     * sample rows are dealt out when its upper quad row is decoded) */
+    /* refinement constants of this lane's block (bit-plane qq = pLSB - 1) */
+    const uint32_t qq_ = (uint32_t)(pLSB - 1) & 31u;
+    const uint32_t ref_new = (1u << qq_) | (1u << ((qq_ - 1) & 31u));
+    const uint32_t ref_keep = z_blk > 2 ? 0xFFFFFFFEu << qq_ : 0xFFFFFFFFu, ref_half = z_blk > 2 ? 1u << ((qq_ - 1) & 31u) : 0u;
+    auto quad_row = [&](int row, uint32_t qi, uint32_t qn) {
         const bool arow = act && row < qh;
-        const uint32_t qi = qi_next;
-        qp += qwp;
-        qi_next = (act && row + 1 < qh) ? *qp : 0u;
         /* field n of the symbol -> bits 0-1 of byte n; R / K / X1: significant / exponent bound / MSB known, bit 0 of byte n */
         const uint32_t pk = qi & 0xFF, pk2 = pk | (pk << 12);
-        const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1, uq = qi >> 8;
+        const uint32_t F = (pk2 | (pk2 << 6)) & 0x03030303u, Fh = F >> 1, uq = (qi >> 8) & 0xFFu;
         const uint32_t R = (F | Fh) & 0x01010101u, K = Fh & 0x01010101u, X1 = F & Fh;
         int kappa = 1;
         if (row > 0) {
@@ -1038,19 +1114,56 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
         const int s0m = -(int)(R & 1), s1m = -(int)((R >> 8) & 1), s2m = -(int)((R >> 16) & 1), s3m = -(int)(R >> 24);
         E1p = (uint32_t)(32 - __clz((int)(v1 | 1))) & (uint32_t)s1m;     /* bottom-left and bottom-right feed the next row */
         E3p = (uint32_t)(32 - __clz((int)(v3 | 1))) & (uint32_t)s3m;
-        /* rows 2 * row and 2 * row + 1 of the refinement masks; this quad's columns are 2 q and 2 q + 1 */
-        uint64_t Rt = 0, Gt = 0, Qt = 0, Rb = 0, Gb = 0, Qb = 0;
-        if (REFINE && rb && row < qh) {
-            const uint64_t *r = rb + (size_t)6 * row * HT_REF_STRIDE;       /* (layout: k_ht_refine) */
-            Rt = r[0] >> (2 * q); Gt = r[HT_REF_STRIDE] >> (2 * q); Qt = r[2 * HT_REF_STRIDE] >> (2 * q);
-            if (2 * row + 1 < h) { Rb = r[3 * HT_REF_STRIDE] >> (2 * q); Gb = r[4 * HT_REF_STRIDE] >> (2 * q); Qb = r[5 * HT_REF_STRIDE] >> (2 * q); }
+        /* the refinement decisions of this quad's samples: bit 0 / 1 = column 2 q / 2 q + 1.  SigProp (newly significant, sign)
+         * from k_ht_refine's masks in LDS; MagRef here: the pass visits a stripe of four sample rows column by column
+         * (:1137-1185), one bit per sample the cleanup pass made significant, so a lane's eight samples of the stripe take
+         * CONSECUTIVE bits, and where they start is a prefix sum of the significant counts over the lanes of the block */
+        uint32_t Rt = 0, Gt = 0, Qt = 0, Rb = 0, Gb = 0, Qb = 0;
+        if (REFINE) {
+            if (!(row & 1)) {
+                uint32_t rt = lut_rho[qi & 0xFFu], rbm = lut_rho[qn & 0xFFu];
+                if (2 * row + 1 >= h) rt &= 5u;                            /* odd heights: the lower sample row of the last quad row is outside */
+                if (2 * row + 3 >= h) rbm &= 5u;
+                if (!(refined && z_blk > 2 && row < qh)) rt = 0;
+                if (!(refined && z_blk > 2 && row + 1 < qh)) rbm = 0;
+                /* stream order inside the lane: column 2 q rows 0..3, then column 2 q + 1 (quad samples: 0 1 | 2 3, row = n & 1) */
+                const uint32_t c0 = (rt & 3u) | ((rbm & 3u) << 2), c1 = (rt >> 2) | (rbm & 0xCu);
+                const uint32_t cnt = (uint32_t)__builtin_popcount(c0 | (c1 << 4));
+                const uint32_t inc = seg_incl_scan_u32<LPB>(cnt);
+                const uint32_t mp = mr_pos + inc - cnt;
+                mr_pos += seg_last<LPB>(inc);
+                const uint32_t wi = min(mp >> 5, mr_words - 2);
+                const uint32_t bits = __builtin_amdgcn_alignbit(mr[wi + 1], mr[wi], mp);
+                const uint32_t d0 = lut_dep[(c0 << 4) | (bits & 15u)];
+                const uint32_t d1 = lut_dep[(c1 << 4) | ((bits >> __builtin_popcount(c0)) & 15u)];
+                Qt = (d0 & 1u) | ((d1 & 1u) << 1);                         /* row 0 of the stripe */
+                Qb = ((d0 >> 1) & 1u) | (d1 & 2u);                         /* row 1 */
+                dB = (d0 >> 2) | ((d1 >> 2) << 2);                         /* rows 2, 3: the quad row below */
+            } else {
+                Qt = (dB & 1u) | ((dB >> 1) & 2u);
+                Qb = ((dB >> 1) & 1u) | ((dB >> 2) & 2u);
+            }
+            if (refined && row < qh) {
+                const uint32_t *r = rg + (size_t)(2 * row) * 2 * MW;
+                if (MW == 1) {
+                    Rt = r[0] >> (2 * q); Gt = r[1] >> (2 * q);
+                    if (2 * row + 1 < h) { Rb = r[2] >> (2 * q); Gb = r[3] >> (2 * q); }
+                } else {
+                    Rt = (uint32_t)((((uint64_t)r[1] << 32) | r[0]) >> (2 * q)); Gt = (uint32_t)((((uint64_t)r[3] << 32) | r[2]) >> (2 * q));
+                    if (2 * row + 1 < h) { Rb = (uint32_t)((((uint64_t)r[5] << 32) | r[4]) >> (2 * q)); Gb = (uint32_t)((((uint64_t)r[7] << 32) | r[6]) >> (2 * q)); }
+                }
+            }
         }
         auto sample = [&](uint32_t v, int sm, uint32_t nsig, uint32_t sgn, uint32_t mrb) -> uint32_t {   /* mu (:407-427) -> dequantisation */
             uint32_t mu = (((((v >> 1) + 1u) << pLSB) | halfbit) | (v << 31)) & (uint32_t)sm;
             if (REFINE) {
-                const int qq = (pLSB - 1) & 31;
-                if (nsig & 1) mu |= (1u << qq) | (1u << ((qq - 1) & 31)) | (sgn << 31);
-                if (z_blk > 2 && sm) { mu &= (0xFFFFFFFEu | (mrb & 1)) << qq; mu |= 1u << ((qq - 1) & 31); }
+                /* SigProp made the sample significant: magnitude bit qq, the half bit below it, its sign (:1066-1100); MagRef
+                 * (blocks with the third pass, samples the cleanup pass made significant): bit qq replaced by the pass's bit,
+                 * the half bit moves down (:1160-1185).  Both as masks, no branch */
+                mu |= ((sgn << 31) | ref_new) & (uint32_t)-(int)(nsig & 1u);
+                const uint32_t keep = ((mrb & 1u) << qq_) | ref_keep | ~(uint32_t)sm;      /* all ones where MagRef does not apply */
+                mu = (mu & keep) | (ref_half & (uint32_t)sm);
+                if (TRANSFORM == J2K_DWT97) return __float_as_uint((float)(mu & 0x7FFFFFFFu) * fscale) | (mu & 0x80000000u);
                 return ht_dequant(mu, TRANSFORM, M_b, 0, fscale, i_step);
             }
             if (TRANSFORM == J2K_DWT53) {
@@ -1069,13 +1182,12 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
                 return ht_dequant(mu, TRANSFORM, M_b, 0, fscale, i_step);
             }
         };
-        const uint32_t o0 = sample(v0, s0m, (uint32_t)Rt, (uint32_t)Gt & 1, (uint32_t)Qt);
-        const uint32_t o1 = sample(v1, s1m, (uint32_t)Rb, (uint32_t)Gb & 1, (uint32_t)Qb);
-        const uint32_t o2 = sample(v2, s2m, (uint32_t)(Rt >> 1), (uint32_t)(Gt >> 1) & 1, (uint32_t)(Qt >> 1));
-        const uint32_t o3 = sample(v3, s3m, (uint32_t)(Rb >> 1), (uint32_t)(Gb >> 1) & 1, (uint32_t)(Qb >> 1));
+        const uint32_t o0 = sample(v0, s0m, Rt, Gt & 1, Qt);
+        const uint32_t o1 = sample(v1, s1m, Rb, Gb & 1, Qb);
+        const uint32_t o2 = sample(v2, s2m, Rt >> 1, (Gt >> 1) & 1, Qt >> 1);
+        const uint32_t o3 = sample(v3, s3m, Rb >> 1, (Gb >> 1) & 1, Qb >> 1);
         const bool two = 2 * row + 1 < h;
-        /* a fixed number of stores per row behind the prefetch of the next row's symbols (vmcnt(N) stays exact): lanes
-         * and rows with nothing to write aim at a scratch line */
+        /* lanes and rows with nothing to write aim at a scratch line */
         if (pairs) {
             u32x2 t, bt;
             t.x = o0; t.y = o2; bt.x = o1; bt.y = o3;
@@ -1088,6 +1200,22 @@ k_ht_decode_multi(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_
             *((arow && two && c2) ? prow + stride + 1 : sink) = o3;
         }
         prow += 2 * stride;
+    };
+    if (pre) {                                               /* two rows per register, no load in the loop */
+        for (int k = 0; 2 * k < rows; k++) {
+            uint32_t s2 = sy[k];                             /* (uniform index) */
+            s2 = (act && 2 * k < qh) ? s2 : 0u;              /* rows past this lane's block; a rejected block */
+            s2 = (2 * k + 1 < qh) ? s2 : s2 & 0xFFFFu;
+            quad_row(2 * k, s2 & 0xFFFFu, s2 >> 16);
+            if (2 * k + 1 < rows) quad_row(2 * k + 1, s2 >> 16, 0u);
+        }
+    } else {
+        for (int row = 0; row < rows; row++) {
+            const uint32_t qi = qi_next;
+            qp += qwp;
+            qi_next = (act && row + 1 < qh) ? *qp : 0u;
+            quad_row(row, qi, qi_next);
+        }
     }
     /* a block whose U ran past maxbp is rejected as a whole (:862-868): zero it, whole wave per block */
 #pragma unroll
@@ -1581,10 +1709,6 @@ __device__ __forceinline__ uint32_t ht_unstuff_forward7(const uint8_t *__restric
     return base;
 }
 
-/* words of the un-stuffed arrays of one block: [0, ht_nsw) VLC resp. MEL, [ht_nsw, ht_nsw + ht_nsp) SigProp
- * resp. MagRef (blocks with refinement passes); both fit the block's byte region (J2K_BLOCK_PAD) */
-__host__ __device__ inline uint32_t ht_nsw(uint32_t Scup) { return (Scup * 8 + 31) / 32 + 2; }
-__host__ __device__ inline uint32_t ht_nsp(uint32_t Lref) { return (Lref * 8 + 31) / 32 + 3; }
 
 __global__ void __launch_bounds__(64)
 k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
@@ -1674,8 +1798,12 @@ k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__
  * dequantise.  They are stored LANE-INTERLEAVED per wavefront of this kernel: mask k of row y of the block on lane l
  * sits at refbits[roff[block] + (3 y + k) * 64], roff[block] = base of the wave + l (htj2k_device.hip: ref_layout), so
  * that a store of the wave is 512 contiguous bytes.  ref_list[i] = block index. */
-template <typename MT>
-__global__ void __launch_bounds__(64)
+/* MAGREF = false: the MagSgn kernel deals out the MagRef bits itself (k_ht_decode_multi: the pass is a prefix sum there) and
+ * the third mask of a row stays zero */
+/* (six waves per SIMD where the state fits 80 registers without spilling -- 32-bit masks, SigProp only: the C3 case, 0.72 ->
+ * 0.50 ms with both -- four otherwise; the kernel waits on scattered loads, so waves in flight are what it lives on) */
+template <typename MT, bool MAGREF>
+__global__ void __launch_bounds__(64, (sizeof(MT) == 4 && !MAGREF) ? 6 : 4)
 k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ ref_list, int nref,
             const uint8_t *__restrict__ bytes, const ht_sym_t *__restrict__ qsym, const uint32_t *__restrict__ qoff,
             const uint32_t *__restrict__ vlc_u, const uint32_t *__restrict__ mel_u,
@@ -1743,7 +1871,7 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
         }
     } sp, mr;
     sp.init(spw, nsp);
-    mr.init(mrw, nsp);
+    if (MAGREF) mr.init(mrw, nsp);
 
     /* significance rows of quad row qy: the symbols of a row are read as dwords (two quads; rows are padded to an even
      * number of quads and start on a dword), four at a time where the row pitch allows 16-byte loads */
@@ -1833,7 +1961,7 @@ k_ht_refine(const J2kBlock *__restrict__ blocks, const uint32_t *__restrict__ re
                 }
             }
         }
-        if (z_blk > 2) {                                               /* MagRef: one bit per sample the cleanup pass made significant */
+        if (MAGREF && z_blk > 2) {                                     /* MagRef: one bit per sample the cleanup pass made significant */
             for (int j = 0; j < w; j++) {
                 if (mr.cnt <= 32) mr.top_up();
                 if ((S0 >> j) & 1) Q0 |= (MT)mr.get() << j;

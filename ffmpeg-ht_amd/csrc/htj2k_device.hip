@@ -213,6 +213,7 @@ struct htj2k_job {
     std::vector<uint32_t> reflist, roff;   /* blocks with refinement passes that k_ht_refine handles; first mask of each in d_refbits */
     size_t nrefmasks = 0;
     uint32_t ref_max_w = 0;            /* widest block of reflist: k_ht_refine keeps 32-bit row masks when it is at most 32 */
+    uint32_t ref_max_h = 0;            /* tallest: k_ht_decode_multi stages the SigProp masks of its blocks in LDS (at most 64 rows) */
     uint32_t max_lref = 0;
     size_t nquads = 0;
     HtLds lds_ext;                     /* LDS layout of k_ht_decode<true> (no VLC windows, no tables) */
@@ -753,17 +754,20 @@ static int ht_lds_layout(htj2k_ctx *c, uint32_t max_p, uint32_t max_s, uint32_t 
  * go: the block on lane l of the kernel's wave g (reflist[64 g + l]) has mask k of row y at
  * roff[block] + (3 y + k) * HT_REF_STRIDE, roff[block] = base of wave g + l; a wave takes 64 * 3 * (its tallest block)
  * words.  Returns the total in 64-bit words; *max_w = the widest such block. */
-static size_t ref_layout(const J2kBlock *blocks, size_t nblocks, std::vector<uint32_t> &reflist, std::vector<uint32_t> &roff, uint32_t *max_w)
+static size_t ref_layout(const J2kBlock *blocks, size_t nblocks, std::vector<uint32_t> &reflist, std::vector<uint32_t> &roff, uint32_t *max_w,
+                         uint32_t *max_h = nullptr)
 {
     reflist.clear();
     roff.assign(nblocks + 1, 0);
     *max_w = 0;
+    if (max_h) *max_h = 0;
     for (size_t i = 0; i < nblocks; i++) {
         const J2kBlock &b = blocks[i];
         const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
         if (b.npasses && !(b.flags & J2K_BLK_PART1) && b.npasses - plhd > 1 && b.w <= 64 && b.roi_shift == 0) {
             reflist.push_back((uint32_t)i);
             if (b.w > *max_w) *max_w = b.w;
+            if (max_h && b.h > *max_h) *max_h = b.h;
         }
     }
     size_t nm = 0;
@@ -1128,7 +1132,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         j->nquads = q;
         /* blocks with SigProp / MagRef passes go through k_ht_refine (one lane per block) when
          * k_ht_decode's row-mask path can take them: up to 64 columns, no ROI shift */
-        const size_t nm = ref_layout(j->blocks.data(), j->blocks.size(), j->reflist, j->roff, &j->ref_max_w);
+        const size_t nm = ref_layout(j->blocks.data(), j->blocks.size(), j->reflist, j->roff, &j->ref_max_w, &j->ref_max_h);
         if (nm > 0xFFFFFF00ull) return HTJ2K_ERR_PATCHWELCOME;
         j->nrefmasks = nm;
     }
@@ -1223,6 +1227,9 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
          * (C4 gray16 1.50 -> 1.64 ms per 16 frames), with short ones it is not (int32 C2 2.93 -> 2.74, C3 2.15 -> 1.65) */
         const size_t multi_lds_max = getenv("HTJ2K_MULTI_LDS") ? (size_t)atoi(getenv("HTJ2K_MULTI_LDS")) : 12 * 1024;
         if (mok && (size_t)j->multi_nb * (j->lds_ext.ms_words + 4) * 4 > multi_lds_max) j->multi_nb = 0;
+        /* blocks with refinement passes: their SigProp masks and MagRef bits are staged in LDS, up to 64 sample rows */
+        if (j->multi_nb && !j->reflist.empty() &&
+            (j->ref_max_h > 64 || ht_multi_refine_lds(j->multi_nb, ht_nsp(j->max_lref), j->ref_max_h) > 24 * 1024)) j->multi_nb = 0;
     }
     if ((r = j->d_desc.ensure(j->h_desc.size() + 64)) < 0) return r;
     HIP_TRY(c, hipEventRecord(j->ev[0], j->stream));
@@ -1519,12 +1526,17 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                    (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
                                    (const uint16_t *)c->d_tables, (ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, j->max_qw,
                                    (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p, (uint32_t *)j->d_qsym.p + j->nquads / 2 + 32);
-                if (!j->reflist.empty())
-                    hipLaunchKernelGGL(j->ref_max_w <= 32 ? k_ht_refine<uint32_t> : k_ht_refine<uint64_t>, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
+                const bool multi_run = !(j->coef_is16 && j->pair_ok && c->ht_pair) && !j->coef_is16 && j->multi_nb && c->ht_multi;
+                if (!j->reflist.empty()) {
+                    /* k_ht_decode_multi deals out the MagRef bits itself; the column-per-lane kernel takes them from k_ht_refine */
+                    auto kref = j->ref_max_w <= 32 ? (multi_run ? k_ht_refine<uint32_t, false> : k_ht_refine<uint32_t, true>)
+                                                   : (multi_run ? k_ht_refine<uint64_t, false> : k_ht_refine<uint64_t, true>);
+                    hipLaunchKernelGGL(kref, dim3(((unsigned)j->reflist.size() + 63) / 64), dim3(64), 0, j->stream,
                                        (const J2kBlock *)j->d_blocks.p, (const uint32_t *)j->d_reflist.p, (int)j->reflist.size(),
                                        (const uint8_t *)j->d_bytes.p, (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p,
                                        (const uint32_t *)j->d_vlcu.p, (const uint32_t *)j->d_melu.p,
                                        (uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p);
+                }
                 j->ht_bpw = (j->coef_is16 && j->pair_ok && c->ht_pair) ? 2 : (!j->coef_is16 && j->multi_nb && c->ht_multi) ? j->multi_nb : 1;
                 if (j->coef_is16 && j->pair_ok && c->ht_pair)
                     hipLaunchKernelGGL(k_ht_decode_pair, dim3((nblocks + 1) / 2), dim3(64), 2 * (j->lds_ext.ms_words + 4) * 4, j->stream,
@@ -1534,7 +1546,8 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                        (uint32_t *)j->d_coef.p + j->nsamples + 32);
                 else if (!j->coef_is16 && j->multi_nb && c->ht_multi) {
                     const int nb = j->multi_nb;
-                    const size_t lds = (size_t)nb * (j->lds_ext.ms_words + 4) * 4;
+                    const uint32_t mr_words = j->reflist.empty() ? 0u : ht_nsp(j->max_lref), rg_rows = j->reflist.empty() ? 0u : j->ref_max_h;
+                    const size_t lds = (size_t)nb * (j->lds_ext.ms_words + 4) * 4 + (j->reflist.empty() ? 0 : ht_multi_refine_lds(nb, mr_words, rg_rows));
 #define HT_MULTI_R(NB_, T_, R_) do { \
                         if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode_multi<NB_, T_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                         hipLaunchKernelGGL((k_ht_decode_multi<NB_, T_, R_>), dim3((nblocks + NB_ - 1) / NB_), dim3(64), lds, j->stream, \
@@ -1542,7 +1555,8 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                                            (uint32_t *)j->d_coef.p, (int *)j->d_status.p, j->lds_ext.ms_words, \
                                            (const ht_sym_t *)j->d_qsym.p, (const uint32_t *)j->d_qoff.p, \
                                            (uint32_t *)j->d_coef.p + j->nsamples + 32, \
-                                           (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p); } while (0)
+                                           (const uint64_t *)j->d_refbits.p, (const uint32_t *)j->d_roff.p, \
+                                           (const uint32_t *)j->d_melu.p, mr_words, rg_rows); } while (0)
 #define HT_MULTI(NB_, T_) do { if (j->reflist.empty()) HT_MULTI_R(NB_, T_, false); else HT_MULTI_R(NB_, T_, true); } while (0)
                     if (nb == 4) {
                         if (j->multi_t == J2K_DWT53) HT_MULTI(4, J2K_DWT53); else if (j->multi_t == J2K_DWT97) HT_MULTI(4, J2K_DWT97); else HT_MULTI(4, J2K_DWT97_INT);
@@ -2226,7 +2240,7 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (ht_sym_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq / 2 + 32);
             if (!reflist.empty())
-                hipLaunchKernelGGL(ref_max_w <= 32 ? k_ht_refine<uint32_t> : k_ht_refine<uint64_t>, dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
+                hipLaunchKernelGGL((ref_max_w <= 32 ? k_ht_refine<uint32_t, true> : k_ht_refine<uint64_t, true>), dim3(((unsigned)reflist.size() + 63) / 64), dim3(64), 0, 0,
                                    (const J2kBlock *)db.p, (const uint32_t *)drl.p, (int)reflist.size(), (const uint8_t *)dby.p,
                                    (const ht_sym_t *)dq.p, (const uint32_t *)dqo.p, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p,
                                    (uint64_t *)drb.p, (const uint32_t *)dro.p);
