@@ -53,11 +53,11 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 COPY_CEILING_GBS = 6290.0      # same guide, line 36: float4 copy, 79 % of the spec
 
 
-def committed_traffic(frames_per_step):
+def committed_traffic(frames_per_step, launches_per_step=None):
     """HBM bytes per IDWT launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     process): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the IDWT launches of one step of this same
-    workload (tools/prof_r02.sh + tools/make_profiles.py); None when the batch differs from the profiled one.
-    The newest matching file wins."""
+    workload (tools/prof_round.sh + tools/make_profiles.py); None when the batch, or the number of IDWT launches a
+    step makes, differs from the profiled one.  The newest matching file wins."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
@@ -65,7 +65,9 @@ def committed_traffic(frames_per_step):
             if name.endswith("_idwt_traffic.json"):
                 try:
                     d = json.load(open(os.path.join(pdir, name)))
-                    if d.get("frames_per_step") == frames_per_step:
+                    lps = d.get("idwt_launches_per_step")
+                    if d.get("frames_per_step") == frames_per_step and (
+                            launches_per_step is None or lps is None or abs(lps - launches_per_step) < 1e-6):
                         best = (d["hbm_bytes_per_launch"], name)
                 except (OSError, ValueError, KeyError):
                     pass
@@ -527,7 +529,7 @@ def main():
         info0 = dec.probe(streams[0])
         pk = [m.packet(x) for x in streams]                # zero-copy sends (htj2k_pipe_send_ref): the staging copy is the workers'
 
-        def run_pipe(receive, nwarm=24, nfr=96):
+        def run_pipe(receive, nwarm=48, nfr=96):        # 2 * depth - 1 = 5 jobs of 8 frames exist: all are allocated by frame 40
             pipe = dec.pipe(batch=8, depth=3)
             sent = got = 0
             t0 = None
@@ -578,7 +580,7 @@ def main():
     if rank == 0:
         algorithmic = idwt_launch_bytes / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
         achieved = idwt_launch_hbm / (idwt_launch_ms * 1e-3) / 1e9 if idwt_launch_ms > 0 else 0.0
-        traffic = committed_traffic(args.batch)
+        traffic = committed_traffic(args.batch, nlaunch / max(rsteps, 1))
         res = {
             "metric": "Mpixels/s HTJ2K decode (4K lossless 5/3) at 1/2/4/8 GPU; IDWT HBM GB/s vs peak",
             "value": round(value, 2),
@@ -603,7 +605,10 @@ def main():
                        "distinct_frames": len(streams), "block_errors": block_errors,
                        "sharding": "frames round-robin over ranks, no collective"},
             "roofline": {"bound": "hbm",
-                         "kernel": "k_idwt_stream_ll16 (levels 1-4: 16-bit sub-bands and LL bands) + k_idwt_stream_pack<5/3, 3> "
+                         "kernel": "k_idwt_stream_ll16_x3 (levels 1-3 in one launch) + k_idwt_stream_ll16 (level 4; 16-bit sub-bands "
+                                   "and LL bands) + k_idwt_stream_pack<5/3, 3> (level 5 fused with RCT + rgb24 store)"
+                                   if ll16 and nlaunch == 3 * rsteps else
+                                   "k_idwt_stream_ll16 (levels 1-4: 16-bit sub-bands and LL bands) + k_idwt_stream_pack<5/3, 3> "
                                    "(level 5 fused with RCT + rgb24 store)" if ll16 else
                                    "k_idwt_stream<5/3> (levels 1-4) + k_idwt_stream_pack<5/3, 3> (level 5 fused with RCT + rgb24 store)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -640,7 +645,7 @@ def main():
                      "end_to_end_Mpixel_s_pipeline": round(pipe_rate, 1),
                      "end_to_end_Mpixel_s_pipeline_pinned_frames": round(pipe_rate_pinned, 1),
                      "packets_to_device_frames_Mpixel_s_pipeline": round(pipe_rate_device, 1),
-                     "pipeline": "htj2k_pipe: 96 frames after 24 warm-up, batches of 8, 3 in flight, pageable packets in, "
+                     "pipeline": "htj2k_pipe: 96 (to the device: 192) frames after 48 warm-up, batches of 8, depth 3, pageable packets in, "
                                  "frames out into pageable / page-locked (htj2k_host_alloc) planes",
                      "note": "parse = marker + Tier-2 parse of one frame on one core (no code-block byte is read: the "
                              "packets are uploaded as they are and k_gather builds the byte pool on the device); "

@@ -8,7 +8,7 @@
 # `roofline` and `stage_ms_per_step_one_job` come from, so that the per-kernel averages of the trace can be held against them
 # (the default --jobs 2 pass launches the same kernels on half batches as well).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
@@ -30,6 +30,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cfg_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cfg_write -o cfg -- $CFG > $O/cfg_write.log 2>&1 || exit 1
 echo "configs done"
 python3 $R/tools/gpu_configs.py > $O/configs.log 2>&1 && cp $R/gpurun_out/configs.json $O/configs.json
-bash $R/tools/pmc_ht_r02.sh > $O/pmc_ht.log 2>&1 && cp $R/gpurun_out/r02_ht_sq.csv $O/ht_sq.csv
+bash $R/tools/pmc_ht_${tag}.sh > $O/pmc_ht.log 2>&1 && cp $R/gpurun_out/${tag}_ht_sq.csv $O/ht_sq.csv
 echo "sq done"
 find $O -name "*.csv" | wc -l
