@@ -313,11 +313,11 @@ k_idwt_tile(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ l
 /* lane-to-lane moves of the streaming kernels (dwt_stream.hpp) */
 __device__ __forceinline__ uint32_t dpp_from_left(uint32_t v)    /* lane i <- lane i-1, lane 0 <- 0 */
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);    /* wave_shr:1 */
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);     /* wave_shr:1, bound_ctrl: no `old` value to set up */
 }
 __device__ __forceinline__ uint32_t dpp_from_right(uint32_t v)   /* lane i <- lane i+1, lane 63 <- 0 */
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);    /* wave_shl:1 */
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);     /* wave_shl:1 */
 }
 
 }  // namespace htj2k

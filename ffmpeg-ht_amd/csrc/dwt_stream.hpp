@@ -108,6 +108,49 @@ __device__ __forceinline__ void stream_hlift(uint32_t (&v)[4], bool mirror_l = f
     }
 }
 
+/* ---- 5/3 lifting on pairs of 16-bit samples (PK, below) ----
+ * A dword of a 16-bit band holds two neighbouring samples of that band: of a lane's four positions e0 o0 e1 o1 the register
+ * E = (e0, e1) is the dword it loaded from the low band and O = (o0, o1) the one from the high band.  v_pk_* instructions lift
+ * both pairs at once; the vertical lifting, the RCT and the clip run on the same pairs, so a step takes half the
+ * arithmetic instructions of the 32-bit form and no widening.  Sums wrap at 16 bits: the host starts these kernels only where
+ * interval arithmetic over the bands' M_b and the checked range of the LL band shows that no intermediate can
+ * (htj2k_device.hip, pk16_bounds). */
+/* a wave-uniform pointer, pinned to scalar registers and opaque to the optimiser: `sgpr_ptr(row) + lane_offset` then is a
+ * load with a scalar base and a 32-bit vector offset instead of a 64-bit vector add per load (left alone, the compiler hoists
+ * `base + lane_offset` out of the row loop as a 64-bit vector value and adds the row offset to it with v_lshl_add_u64) */
+typedef __attribute__((address_space(1))) const char g_cchar;
+typedef __attribute__((address_space(1))) const uint32_t g_cu32;
+__device__ __forceinline__ g_cchar *sgpr_ptr(const void *p)               /* p: global memory */
+{
+    uint64_t v = (uint64_t)p;
+    asm("" : "+s"(v));
+    return (g_cchar *)v;
+}
+
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_u16 pk_from(uint32_t v) { return __builtin_bit_cast(pk_u16, v); }
+__device__ __forceinline__ uint32_t pk_bits(pk_u16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk_u16 pk_sar(pk_u16 v, int n) { return __builtin_bit_cast(pk_u16, __builtin_bit_cast(pk_i16, v) >> (short)n); }
+__device__ __forceinline__ uint32_t pk_s1(uint32_t c, uint32_t a, uint32_t b)   /* jpeg2000dwt.c:321-322 on both halves */
+{
+    const pk_u16 two = { 2, 2 };
+    return pk_bits(pk_from(c) - pk_sar(pk_from(a) + pk_from(b) + two, 2));
+}
+__device__ __forceinline__ uint32_t pk_s2(uint32_t c, uint32_t a, uint32_t b)   /* :323-324 */
+{
+    return pk_bits(pk_from(c) + pk_sar(pk_from(a) + pk_from(b), 1));
+}
+/* E = (e0, e1), O = (o0, o1) of every lane; the odd sample left of e0 and the even sample right of o1 come from the
+ * neighbouring lanes (or, at the ends of the line, from the lane itself: the mirror rule of stream_hlift) */
+__device__ __forceinline__ void stream_hlift_pk(uint32_t &E, uint32_t &O, uint32_t sel_l, uint32_t sel_r)
+{
+    /* sel_l / sel_r: the lane's byte selectors for v_perm -- 0x05040302 takes (neighbour's high half, own low half), at the
+     * end of a line 0x05040504 / 0x03020302 repeat the lane's own sample */
+    E = pk_s1(E, __builtin_amdgcn_perm(O, dpp_from_left(O), sel_l), O);  /* (left o1, o0) + (o0, o1) */
+    O = pk_s2(O, E, __builtin_amdgcn_perm(dpp_from_right(E), E, sel_r)); /* (e0, e1) + (e1, right e0) */
+}
+
 /* the components one wave reconstructs in lockstep share the level geometry g of a[0] */
 struct DwtFusedArgs {
     DwtTileArgs a[4];
@@ -135,7 +178,9 @@ struct DwtFusedArgs {
  * element offsets, the buffer read as int16_t), and *ovf is set when a sample does not fit: an LL band of a real
  * picture stays in the picture's range, but nothing bounds what crafted or corrupt coefficients add up to.  The host
  * then runs the transform again with 32-bit LL bands (htj2k_device.hip, job_settle). */
-template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0>
+/* PK (FAST && FUSED, 16-bit sub-bands and LL band, 8-bit output of 8-bit components: OUTK 0 or 2): the whole step on pairs of
+ * 16-bit samples, see stream_hlift_pk */
+template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by,
@@ -144,6 +189,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     /* ll_row0 / out_row0 (FAST 16-bit paths only): the LL input / the output is a window whose first row is row ll_row0 /
      * out_row0 of the band (k_idwt_stream_ll16_x3's LDS windows) */
     using O = LiftOps<TYPE>;
+    static_assert(!PK || (TYPE == J2K_DWT53 && FUSED && FAST && C16 && LL16 && (OUTK == 0 || OUTK == 2)), "PK: the 8-bit fused fast stores of 16-bit jobs");
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
     const DwtLevel g = A[0].g;
     /* the strip: columns [bx tw, bx tw + tw), rows [by th, by th + th) -- or, for callers that cut a level their own way
@@ -172,6 +218,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 #pragma unroll
         for (int k = 0; k < 4; k++) col[k] = LX.idx(pe0 + k);
     }
+    const uint32_t pk_sel_l = mirror_l ? 0x05040504u : 0x05040302u, pk_sel_r = mirror_r ? 0x03020302u : 0x05040302u;
     const uint32_t *llp[NC], *bandp[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -199,6 +246,9 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         for (int r = 0; r < 2; r++) {
             const int ay = (dir > 0 ? min(ye, s_last) : max(ye, s_last)) + r * dir;   /* the one prefetch past the strip re-reads its last rows */
             iy[r] = (ay >= LY.i0 && ay < LY.i1) ? ((ay & 1) ? LY.nl + ((ay - LY.fo) >> 1) : ((ay - LY.fe) >> 1)) : LY.idx(ay);
+            /* wave-uniform, but the reflection's division runs on the vector unit: say so, and the row pointers below stay in
+             * scalar registers */
+            iy[r] = __builtin_amdgcn_readfirstlane(iy[r]);
         }
         /* even absolute rows are vertical-low rows (the reflection keeps the parity): their
          * low-horizontal half is the previous level's output */
@@ -210,12 +260,21 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
              * (s_waitcnt vmcnt(0)) at the bottom of the loop: the next step's loads were not ahead of anything. */
 #pragma unroll
             for (int c = 0; c < NC; c++) {
+                /* a wave-uniform row pointer plus an unsigned 32-bit lane offset: the load takes its base from scalar
+                 * registers and the address costs no vector instruction */
                 const uint16_t *b16 = (const uint16_t *)band_base + A[c].g.plane_off;
-                const uint16_t *brow0 = b16 + (size_t)iy[0] * A[c].g.stride, *brow1 = b16 + (size_t)iy[1] * A[c].g.stride;
-                Lr[c][1] = *(const uint32_t *)(brow0 + col[1]);                 /* col[] are even here: aligned pairs */
-                Hr[c][0] = *(const uint32_t *)(brow1 + col[0]);
-                Hr[c][1] = *(const uint32_t *)(brow1 + col[1]);
-                if (LL16) {
+                g_cchar *brow0 = sgpr_ptr(b16 + (size_t)iy[0] * A[c].g.stride), *brow1 = sgpr_ptr(b16 + (size_t)iy[1] * A[c].g.stride);
+                uint32_t cb0 = (uint32_t)col[0] * 2u, cb1 = (uint32_t)col[1] * 2u;         /* col[] are even here: aligned pairs */
+                /* (instruction selection works block by block: the zero-extension of the offset has to be seen in the block
+                 * of the load, so the offsets are re-made "here" for the compiler) */
+                asm volatile("" : "+v"(cb0), "+v"(cb1));
+                Lr[c][1] = *(g_cu32 *)(brow0 + cb1);
+                Hr[c][0] = *(g_cu32 *)(brow1 + cb0);
+                Hr[c][1] = *(g_cu32 *)(brow1 + cb1);
+                if (LL16 && FUSED) {                           /* (a final level's LL band is in global memory) */
+                    g_cchar *lrow = sgpr_ptr((const uint16_t *)ll_base + A[c].ll_off + (size_t)(iy[0] - ll_row0) * A[c].ll_stride);
+                    Lr[c][0] = *(g_cu32 *)(lrow + cb0);
+                } else if (LL16) {                             /* k_idwt_stream_ll16_x3: global memory or an LDS window */
                     const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)(iy[0] - ll_row0) * A[c].ll_stride;
                     Lr[c][0] = *(const uint32_t *)(lrow + col[0]);
                 } else {
@@ -269,13 +328,17 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     const bool full = ia == 0 && ib == 4;
 
     /* fast fused path: frame geometry and per-component conversion constants in scalars */
-    uint8_t *f_dst = nullptr;
+    uint8_t *f_dst = nullptr, *f_row0 = nullptr;             /* f_row0 + f_xoff: the same address as a wave-uniform row and a lane offset */
+    uint32_t f_xoff = 0;
+    const bool lane_okq = lane >= 1 && xa + 4 <= x_hi;       /* (= lane_ok below) */
     int f_ls = 0, f_dc[3] = { 0, 0, 0 }, f_hi[3] = { 0, 0, 0 }, f_sh[3] = { 0, 0, 0 };
     bool f_mct = false;
     if (FAST && FUSED) {
         const PackComp &C0 = T->c[OUTK >= 2 ? comp0 : 0];
         f_ls = T->out.linesize[C0.out_plane];
         f_dst = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls + (size_t)(C0.out_x + xa) * (OUTK == 0 ? 3 : OUTK == 1 ? 6 : OUTK == 2 ? 1 : 2);
+        f_row0 = T->out.ptr[C0.out_plane] + (size_t)C0.out_y * f_ls;
+        f_xoff = (uint32_t)(lane_okq ? (C0.out_x + xa) * (OUTK == 0 ? 3 : OUTK == 1 ? 6 : OUTK == 2 ? 1 : 2) : 0);
         f_mct = OUTK < 2 && T->mct != 0;
 #pragma unroll
         for (int c = 0; c < (OUTK >= 2 ? 1 : 3); c++) {
@@ -319,6 +382,54 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 for (int c = 0; c < NC; c++) {
                     uint32_t *p = out_base + A[c].out_off + (size_t)y * A[c].out_stride + xa;
                     if (lane_ok) *(uint4 *)p = make_uint4(val[c][0], val[c][1], val[c][2], val[c][3]);
+                }
+            } else if (PK) {
+                /* val[c][0] = (x0, x2), val[c][1] = (x1, x3) of component c.  Components of 8 bits (the host's condition): DC
+                 * shift and clip are "clamp to [-128, 127], flip bit 7 of the byte", and the flip is done on the packed dwords. */
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+                typedef __attribute__((address_space(1))) u32x3_a4 g_u32x3;
+                typedef __attribute__((address_space(1))) uint32_t g_u32;
+                const pk_i16 lo = { -128, -128 }, hi = { 127, 127 };
+                auto clamp8 = [&](uint32_t v) {
+                    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(pk_i16, v), lo), hi));
+                };
+                g_cchar *const rowp = sgpr_ptr(f_row0 + (size_t)y * f_ls);
+                uint32_t xo = f_xoff;
+                asm volatile("" : "+v"(xo));                             /* (see load_rows) */
+                if (OUTK == 0) {
+                    uint32_t e[3], o[3];
+                    if (f_mct) {                                       /* rct_int, jpeg2000dsp.c:78-91, on both pairs */
+                        const pk_u16 y0 = pk_from(val[0][0]), y1 = pk_from(val[0][1]);
+                        const pk_u16 b0 = pk_from(val[NC > 1 ? 1 : 0][0]), b1 = pk_from(val[NC > 1 ? 1 : 0][1]);
+                        const pk_u16 r0 = pk_from(val[NC > 2 ? 2 : 0][0]), r1 = pk_from(val[NC > 2 ? 2 : 0][1]);
+                        const pk_u16 g0 = y0 - pk_sar(r0 + b0, 2), g1 = y1 - pk_sar(r1 + b1, 2);
+                        /* the host's bounds cover r + b and g; g + r and g + b may leave 16 bits and saturate instead, which
+                         * the clip below cannot tell from the true sum */
+                        auto adds = [](pk_u16 a, pk_u16 b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_i16, a), __builtin_bit_cast(pk_i16, b))); };
+                        e[0] = adds(g0, r0); e[1] = pk_bits(g0); e[2] = adds(g0, b0);
+                        o[0] = adds(g1, r1); o[1] = pk_bits(g1); o[2] = adds(g1, b1);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { e[c] = val[c < NC ? c : 0][0]; o[c] = val[c < NC ? c : 0][1]; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { e[c] = clamp8(e[c]); o[c] = clamp8(o[c]); }
+                    /* bytes: e[c] = (c0 . c2 .), o[c] = (c1 . c3 .) -> r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 */
+                    const uint32_t A0 = __builtin_amdgcn_perm(e[1], e[0], 0x06020400);    /* r0 g0 r2 g2 */
+                    const uint32_t B0 = __builtin_amdgcn_perm(o[0], e[2], 0x06020400);    /* b0 r1 b2 r3 */
+                    const uint32_t C0 = __builtin_amdgcn_perm(o[2], o[1], 0x06020400);    /* g1 b1 g3 b3 */
+                    u32x3 w;
+                    w.x = __builtin_amdgcn_perm(B0, A0, 0x05040100) ^ 0x80808080u;       /* A.0 A.1 B.0 B.1 */
+                    w.y = __builtin_amdgcn_perm(A0, C0, 0x07060100) ^ 0x80808080u;       /* C.0 C.1 A.2 A.3 */
+                    w.z = __builtin_amdgcn_perm(C0, B0, 0x07060302) ^ 0x80808080u;       /* B.2 B.3 C.2 C.3 */
+                    if (lane_ok) *(g_u32x3 *)(rowp + xo) = w;
+                    wk[slot][0] = w.x; wk[slot][1] = w.y; wk[slot][2] = w.z;
+                } else {
+                    const uint32_t e = clamp8(val[0][0]), o = clamp8(val[0][1]);
+                    const uint32_t w = __builtin_amdgcn_perm(o, e, 0x06020400) ^ 0x80808080u;   /* x0 x1 x2 x3 */
+                    if (lane_ok) *(g_u32 *)(rowp + xo) = w;
+                    wk[slot][0] = w;
                 }
             } else {
                 int v[4][4];
@@ -436,6 +547,19 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
         uint32_t r_odd[NC][4], r_even[NC][4];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
+            if (PK) {                                          /* the dwords of load_rows are the pairs */
+                stream_hlift_pk(Lc[c][0], Lc[c][1], pk_sel_l, pk_sel_r);
+                stream_hlift_pk(Hc[c][0], Hc[c][1], pk_sel_l, pk_sel_r);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t e = pk_s1(Lc[c][k], Hp[c][k], Hc[c][k]);        /* row ye     */
+                    const uint32_t o = pk_s2(Hp[c][k], Sa[c][k], e);               /* row ye - 1 */
+                    Hp[c][k] = Hc[c][k]; Sa[c][k] = e;
+                    r_odd[c][k] = o; r_even[c][k] = e;
+                }
+                r_odd[c][2] = r_odd[c][3] = r_even[c][2] = r_even[c][3] = 0;
+                continue;
+            }
             if (C16) {                                         /* the dwords of load_rows -> samples */
                 auto lo16 = [](uint32_t v) { return (uint32_t)(int32_t)(int16_t)(v & 0xFFFFu); };
                 auto hi16 = [](uint32_t v) { return (uint32_t)((int32_t)v >> 16); };
@@ -583,14 +707,14 @@ __host__ __device__ inline int stream_fast_outk(const PackTile &T, const DwtLeve
     return -1;
 }
 
-template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0>
+template <int TYPE, int NC, bool FUSED, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
 __device__ __forceinline__ void
 idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by)
 {
     static_assert(!C16 || FASTONLY, "16-bit sub-bands: FASTONLY launches only");
     if (FASTONLY) {
-        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16, OUTK>(A, ll_base, band_base, out_base, T, comp0, th, tw, bx, by);
+        idwt_stream_impl<TYPE, NC, FUSED, true, C16, LL16, OUTK, PK>(A, ll_base, band_base, out_base, T, comp0, th, tw, bx, by);
     } else {                                               /* per-wave choice; all conditions are wave-uniform */
         bool fast = stream_fast_geom(A[0].g);
         if (FUSED) fast = fast && stream_fast_rgb24(*T, A[0].g, NC, comp0);
@@ -608,8 +732,10 @@ idwt_stream_body(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 struct StreamGrid { int gx, gy, nstrips, per_xcd, tw; };
 __device__ __forceinline__ bool stream_strip(const StreamGrid &G, int &bx, int &by, int &bz)
 {
-    const int b = blockIdx.x;
-    const int s = (b & 7) * G.per_xcd + (b >> 3);
+    /* workgroups of several waves (blockDim.x / 64): the waves of one take neighbouring strips -- G.per_xcd is a multiple
+     * of that count -- and so walk down neighbouring column ranges of the same rows together, on one CU */
+    const int wpb = (int)blockDim.x >> 6, b = blockIdx.x;
+    const int s = (b & 7) * G.per_xcd + (b >> 3) * wpb + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   /* (wave-uniform: keep it scalar) */
     if (s >= G.nstrips) return false;
     bx = s % G.gx;
     const int t = s / G.gx;
@@ -631,7 +757,7 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
 }
 
 /* plain 5/3 level of a job with 16-bit sub-bands whose LL bands are 16-bit as well, in and out */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(512)
 k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G,
                    int *__restrict__ ovf, int ovf_bits)
@@ -715,8 +841,8 @@ k_idwt_stream_ll16_x3(const DwtTileArgs *__restrict__ args0, const DwtTileArgs *
 }
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
-template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0>
-__global__ void __launch_bounds__(64)
+template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
+__global__ void __launch_bounds__(C16 ? 512 : 64)
 k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th, StreamGrid G)
 {
@@ -726,7 +852,7 @@ k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__rest
     DwtTileArgs A[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) A[c] = F.a[c];
-    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16, OUTK>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, G.tw, bx, by);
+    idwt_stream_body<TYPE, NC, true, FASTONLY, C16, LL16, OUTK, PK>(A, ll_base, band_base, nullptr, tiles + F.pack_tile, F.comp0, th, G.tw, bx, by);
 }
 
 }  // namespace htj2k

@@ -123,6 +123,7 @@ struct htj2k_ctx {
     int idwt_x3 = 1;                   /* 1: jobs with 16-bit LL bands run the first three 5/3 levels as one launch (k_idwt_stream_ll16_x3) */
     int ht_pair = 1;                   /* 1: jobs with 16-bit sub-bands use k_ht_decode_pair (two blocks per wave, a lane per quad) */
     int ht_multi = 1;                  /* 1: jobs with 32-bit sub-bands whose HT blocks qualify use k_ht_decode_multi (2 or 4 blocks per wave) */
+    int idwt_pk = 1;                   /* 1: fused final 5/3 levels of 8-bit pictures on pairs of 16-bit samples where the bounds allow (pk16_bounds) */
     int ll16_test_bits = 16;           /* tests: an LL sample "overflows" when it does not fit this many bits */
     int ll16 = 1;                      /* 1: such jobs also keep the LL bands between the IDWT levels as int16_t (overflow is detected
                                         * on the device and the transform run again with 32-bit LL bands, job_settle) */
@@ -151,6 +152,8 @@ struct LevelLaunch {                   /* one IDWT launch: all planes (of all fr
     int nc = 0;                        /* 0: table of DwtTileArgs; 1/3/4: table of DwtFusedArgs (fused final level) */
     int outk = -1;                     /* fused level: the fast store all its entries qualify for (stream_fast_outk), -1: general path */
     bool all_fast = false;             /* every entry qualifies for the streaming kernels' fast path */
+    int pk_bits = 0;                   /* fused 5/3 level with an 8-bit fast store: the packed 16-bit kernel is exact when its LL input fits
+                                        * this many bits (pk16_bounds); 0: not at all */
 };
 
 struct FrameSlot {                     /* one frame of a batch */
@@ -226,6 +229,9 @@ struct htj2k_job {
     std::vector<uint8_t> plane_fused;          /* per tilecomp: the last IDWT run never wrote its final plane */
     bool any_fusable = false;
     /* k_idwt_stream_ll16_x3: the first three 5/3 levels of every plane in one launch (jobs with 16-bit LL bands) */
+    int pk_used = 0;                   /* the last run launched a packed final level: the LL bands were checked against this many bits */
+    bool pk_run = false;               /* this run takes the packed kernels where a launch qualifies (the knob idwt_pk) */
+    int pk_bits = 0;                   /* the LL bands of this job must fit this many bits for its packed 16-bit final levels (0: none) */
     bool x3_ok = false;
     size_t x3_tab[3] = { 0, 0, 0 };            /* the three levels' DwtTileArgs tables in d_desc (same planes, same order) */
     int x3_count = 0, x3_lh[3] = { 0, 0, 0 }, x3_lv2 = 0;
@@ -326,6 +332,8 @@ extern "C" int htj2k_open(const htj2k_opts *opts, htj2k_ctx **out)
     if (m && !strcmp(m, "stream")) c->idwt_mode = 3;
     const char *l16 = getenv("HTJ2K_LL16");
     if (l16) c->ll16 = atoi(l16) ? 1 : 0;
+    const char *pk = getenv("HTJ2K_PK");
+    if (pk) c->idwt_pk = atoi(pk) ? 1 : 0;
     const char *fz = getenv("HTJ2K_FUSE");
     if (fz) c->fuse_pack = atoi(fz) != 0;
     *out = c;
@@ -352,6 +360,7 @@ extern "C" int htj2k_set_int(htj2k_ctx *c, const char *name, int value)
     if (!strcmp(name, "coef16")) { c->coef16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_pair")) { c->ht_pair = value ? 1 : 0; return 0; }
     if (!strcmp(name, "idwt_x3")) { c->idwt_x3 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "idwt_pk")) { c->idwt_pk = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ht_multi")) { c->ht_multi = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16")) { c->ll16 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ll16_test_bits")) { if (value < 2 || value > 16) return HTJ2K_ERR_EINVAL; c->ll16_test_bits = value; return 0; }
@@ -787,6 +796,102 @@ static void push_bytes(std::vector<uint8_t> &v, const void *p, size_t n)
 }
 
 /* descriptor tables for the IDWT launches and the pack stage */
+/* ---- packed 16-bit final level (dwt_stream.hpp, PK): when is it exact? ----
+ * The kernel computes the horizontal and vertical 5/3 lifting of the final level, the inverse RCT and the clip on pairs of
+ * 16-bit samples with wrapping sums.  It equals the 32-bit arithmetic of the reference exactly when no intermediate leaves
+ * 16 bits.  What bounds the inputs: a reversible HT coefficient is a 31-bit magnitude shifted down by 31 - M_b
+ * (jpeg2000dec.c:2135-2144), so |coefficient| <= 2^M_b - 1 whatever the block's bytes hold; and the LL band is the output
+ * of the level below, which the kernels that write it check against `bits` bits (their `ovf` flag: a job that fails runs
+ * again with int32 LL bands and the 32-bit kernels).  Interval arithmetic through the step -- every sum, every shifted sum --
+ * says whether a given `bits` is enough.  bound() returns the largest magnitude of a component's output samples, or -1. */
+static long pk16_lift_bound(long ll, long hl, long lh, long hh)
+{
+    const long LIM = 32767;
+    bool ok = true;
+    auto s1 = [&](long c0, long a) { if (2 * a + 2 > LIM) ok = false; return c0 + (2 * a + 2) / 4; };   /* c - ((a + b + 2) >> 2) */
+    auto s2 = [&](long c0, long a) { if (2 * a > LIM) ok = false; return c0 + a; };                     /* c + ((a + b) >> 1) */
+    const long e = s1(ll, hl), o = s2(hl, e);              /* horizontal, vertical-low rows */
+    const long eh = s1(lh, hh), oh = s2(hh, eh);           /* horizontal, vertical-high rows */
+    const long re0 = s1(e, eh), ro0 = s2(eh, re0);         /* vertical, even columns */
+    const long re1 = s1(o, oh), ro1 = s2(oh, re1);         /* vertical, odd columns */
+    const long m = std::max(std::max(re0, ro0), std::max(re1, ro1));
+    return ok && m <= LIM && e <= LIM && o <= LIM && eh <= LIM && oh <= LIM ? m : -1;
+}
+static bool pk16_bounds(const long (*B)[4], int nc, bool rct)     /* B[c] = { LL, HL, LH, HH } magnitude bounds of component c */
+{
+    long bc[3] = { 0, 0, 0 };
+    for (int c = 0; c < nc; c++)
+        if ((bc[c] = pk16_lift_bound(B[c][0], B[c][1], B[c][2], B[c][3])) < 0) return false;
+    if (rct) {                                              /* g = y - ((cr + cb) >> 2); g + cr and g + cb saturate */
+        if (bc[1] + bc[2] > 32767) return false;
+        if (bc[0] + (bc[1] + bc[2]) / 4 + 1 > 32767) return false;
+    }
+    return true;
+}
+
+static void pk16_eligibility(htj2k_job *j)
+{
+    j->pk_bits = 0;
+    for (LevelLaunch &L : j->launches_fused) L.pk_bits = 0;
+    if (!j->coef16_ok) return;
+    const int ntc = (int)j->tilecomps.size();
+    /* the largest M_b among the blocks of each quadrant of every plane's final level: 0 the LL quadrant (the LL band itself
+     * when the plane has one level), 1 HL, 2 LH, 3 HH */
+    std::vector<std::pair<uint32_t, int>> start(ntc);
+    for (int t = 0; t < ntc; t++) start[t] = { j->tilecomps[t].plane_off, t };
+    std::sort(start.begin(), start.end());
+    auto plane_of = [&](uint32_t off) {
+        auto it = std::upper_bound(start.begin(), start.end(), std::make_pair(off, 1 << 30));
+        return it == start.begin() ? -1 : (it - 1)->second;
+    };
+    std::vector<uint8_t> mb((size_t)ntc * 4, 0);
+    for (const J2kBlock &b : j->blocks) {
+        const int t = plane_of(b.plane_off);
+        if (t < 0) return;
+        const J2kTileComp &tc = j->tilecomps[t];
+        const int lev = tc.ndeclevels - 1;
+        if (lev < 0 || tc.w <= 0) return;
+        const uint32_t off = b.plane_off - tc.plane_off;
+        const int x = (int)(off % (uint32_t)tc.w), y = (int)(off / (uint32_t)tc.w);
+        const int mh = tc.mod[lev][0], mv = tc.mod[lev][1];
+        const int nlx = ((mh + tc.linelen[lev][0] + 1) >> 1) - ((mh + 1) >> 1), nly = ((mv + tc.linelen[lev][1] + 1) >> 1) - ((mv + 1) >> 1);
+        uint8_t &m = mb[(size_t)t * 4 + (x >= nlx ? 1 : 0) + (y >= nly ? 2 : 0)];
+        if (b.M_b > m) m = b.M_b;
+    }
+    int job_bits = 16;
+    for (LevelLaunch &L : j->launches_fused) {
+        if (L.nc == 0 || L.type != J2K_DWT53 || !(L.outk == 0 || L.outk == 2)) continue;
+        const DwtFusedArgs *fa = (const DwtFusedArgs *)(j->h_desc.data() + L.table_off);
+        int bits = 16;
+        for (int i = 0; i < L.count && bits; i++) {
+            const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + fa[i].pack_tile;
+            const bool rct = L.outk == 0 && PT->mct != 0;
+            int tcs[3];
+            bool ok = PT->precision == 8;
+            for (int cc = 0; cc < L.nc && ok; cc++) {
+                tcs[cc] = plane_of(fa[i].a[cc].g.plane_off);
+                ok = tcs[cc] >= 0 && j->tilecomps[tcs[cc]].plane_off == fa[i].a[cc].g.plane_off && PT->c[L.outk == 2 ? fa[i].comp0 : cc].cbps == 8;
+            }
+            int k = 0;
+            for (k = ok ? bits : 0; k >= 10; k--) {           /* below 10 bits the LL band of an ordinary 8-bit picture may not fit */
+                long B[3][4];
+                for (int cc = 0; cc < L.nc; cc++) {
+                    const uint8_t *m = &mb[(size_t)tcs[cc] * 4];
+                    /* one level: the LL band is the block decoder's, bounded by its own M_b, and nothing checks it */
+                    B[cc][0] = L.level == 0 ? (1L << m[0]) - 1 : 1L << (k - 1);
+                    for (int q = 1; q < 4; q++) B[cc][q] = (1L << m[q]) - 1;
+                }
+                if (pk16_bounds(B, L.nc, rct)) break;
+                if (L.level == 0) { k = 0; break; }
+            }
+            bits = k >= 10 ? k : 0;
+        }
+        L.pk_bits = bits;
+        if (bits && L.level > 0) job_bits = std::min(job_bits, bits);
+    }
+    j->pk_bits = job_bits;
+}
+
 static int build_descriptors(htj2k_ctx *c, htj2k_job *j)
 {
     const int ntc = (int)j->tilecomps.size();
@@ -1204,6 +1309,7 @@ extern "C" int htj2k_job_upload(htj2k_ctx *c, htj2k_job *j)
         }
         for (size_t i = 0; ok && i < j->tile_fusable.size(); i++) ok = j->tile_fusable[i] != 0;
         j->coef16_ok = ok;
+        pk16_eligibility(j);
         for (size_t i = 0; ok && i < j->blocks.size(); i++) {
             const J2kBlock &b = j->blocks[i];
             ok = !(b.w & 1) && !(b.stride & 1) && !(b.plane_off & 1);
@@ -1328,15 +1434,37 @@ static int stream_strip_cols(int max_lh, int out_bytes)
     return STREAM_TW;
 }
 
-static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count, int tw = STREAM_TW)
+static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count, int tw = STREAM_TW, int wpb = 1)
 {
     StreamGrid G;
     G.tw = tw;
     G.gx = (max_lh + tw - 1) / tw;
     G.gy = (max_lv + th - 1) / th;
     G.nstrips = G.gx * G.gy * count;
-    G.per_xcd = (G.nstrips + 7) / 8;
+    G.per_xcd = ((G.nstrips + 7) / 8 + wpb - 1) / wpb * wpb;      /* launches of 8 * per_xcd / wpb workgroups of wpb waves */
     return G;
+}
+/* Waves per workgroup of the streaming kernels that take more than one (the 16-bit FASTONLY ones).  Eight neighbouring
+ * strips -- half a row of a 4K plane -- as one workgroup walk down the same rows of neighbouring column ranges together on one
+ * CU, so what they ask of a DRAM page comes close together in time: final level of C2 740 -> 711 us with the 32-bit arithmetic
+ * (4 waves per SIMD), 774 -> 660 with the packed one at two such workgroups per CU (below); 6 or 10 waves, which do not divide
+ * the 16 strips of a row, 718 / 724; 16 waves 700-707; level 4 250 -> 238-243 us. */
+static int stream_wpb(int max_lh, int tw)
+{
+    static const int e = getenv("HTJ2K_WPB") ? atoi(getenv("HTJ2K_WPB")) : 0;
+    if (e >= 1 && e <= 8) return e;
+    return std::max(1, std::min(8, (max_lh + tw - 1) / tw));
+}
+/* Dynamic LDS the packed final-level kernel is launched with -- it uses none: it is there to keep the CU at 16 waves.  The
+ * kernel needs 61 VGPRs and would run 8 waves per SIMD, and with that many strips in flight the memory system does worse:
+ * C2 final level, one wave per workgroup, 792 us at 32 waves per CU, 754 at 20, 732 at 16, 718 at 12, 757 at 8; workgroups
+ * of eight waves 713 us at three per CU, 660-683 at two, 739 at one. */
+static int stream_pk_lds(int wpb)
+{
+    static const int e = getenv("HTJ2K_PK_LDS") ? atoi(getenv("HTJ2K_PK_LDS")) : -1;
+    if (e >= 0) return e;
+    const int per_cu = wpb >= 8 ? 2 : wpb >= 4 ? 3 : 12 / wpb;          /* workgroups */
+    return (160 * 1024 / per_cu) & ~1023;
 }
 
 template <int TYPE>
@@ -1357,15 +1485,22 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
     }
 }
 
+/* how many bits the 16-bit LL bands of a job must fit: 16, fewer where a packed final level needs it (pk16_eligibility) or a test says so */
+static int ll16_check_bits(const htj2k_ctx *c, const htj2k_job *j)
+{
+    return std::min(c->ll16_test_bits, c->idwt_pk && j->pk_bits ? j->pk_bits : 16);
+}
+
 template <int TYPE>
 static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, const uint32_t *ll, uint32_t *out)
 {
     if (TYPE == J2K_DWT53 && j->ll16_run && c->idwt_mode >= 3 && L.min_l >= 2) {    /* 16-bit sub-bands and LL bands, in and out */
         const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
-        const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, stream_strip_cols(L.max_lh, 2));
-        hipLaunchKernelGGL(k_idwt_stream_ll16, dim3(8 * G.per_xcd), dim3(64), 0, j->stream,
+        const int tw = stream_strip_cols(L.max_lh, 2), wpb = stream_wpb(L.max_lh, tw);
+        const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, tw, wpb);
+        hipLaunchKernelGGL(k_idwt_stream_ll16, dim3(8 * G.per_xcd / wpb), dim3(64 * wpb), 0, j->stream,
                            (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
-                           (int *)j->d_status.p + j->blocks.size(), c->ll16_test_bits);
+                           (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
         return;
     }
     launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
@@ -1377,16 +1512,30 @@ template <int TYPE>
 static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_t *ll)
 {
     const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
-    const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count,
-                                     stream_strip_cols(L.max_lh, L.outk == 0 ? 3 : L.outk == 1 ? 6 : L.outk == 2 ? 1 : L.outk == 3 ? 2 : 0));
-    dim3 g(8 * G.per_xcd);
+    const int tw = stream_strip_cols(L.max_lh, L.outk == 0 ? 3 : L.outk == 1 ? 6 : L.outk == 2 ? 1 : L.outk == 3 ? 2 : 0);
+    const int wpb = TYPE == J2K_DWT53 && j->coef_is16 ? stream_wpb(L.max_lh, tw) : 1;
+    const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, tw, wpb);
+    dim3 g(8 * G.per_xcd / wpb);
+    const dim3 blk(64 * wpb);
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
-#define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G)
+#define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, (C16_) ? blk : dim3(64), 0, j->stream, tab, ll, band, tiles, th, G)
     if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: every fused launch is a fast-store one */
         const bool l0 = L.level == 0 || j->ll16_run;      /* the LL band is 16-bit: the block decoder's, or the level below wrote it so */
-        if (L.outk == 0) { if (l0) FUSED_FAST(3, true, true, 0); else FUSED_FAST(3, true, false, 0); }
+        const bool pk = l0 && L.pk_bits && j->pk_run;   /* pairs of 16-bit samples all the way (pk16_eligibility) */
+        const int pk_lds = pk ? stream_pk_lds(wpb) : 0;
+        if (pk && (L.outk == 0 || L.outk == 2)) j->pk_used = L.level == 0 ? 16 : std::min(16, j->pk_bits);
+        if (pk && L.outk == 0) {
+            if (pk_lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_idwt_stream_pack<J2K_DWT53, 3, true, true, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pk_lds);
+            hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 3, true, true, true, 0, true>), g, blk, pk_lds, j->stream, tab, ll, band, tiles, th, G);
+        } else if (pk && L.outk == 2) {
+            if (pk_lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_idwt_stream_pack<J2K_DWT53, 1, true, true, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pk_lds);
+            hipLaunchKernelGGL((k_idwt_stream_pack<J2K_DWT53, 1, true, true, true, 2, true>), g, blk, pk_lds, j->stream, tab, ll, band, tiles, th, G);
+        }
+        else if (L.outk == 0) { if (l0) FUSED_FAST(3, true, true, 0); else FUSED_FAST(3, true, false, 0); }
         else if (L.outk == 1) { if (l0) FUSED_FAST(3, true, true, 1); else FUSED_FAST(3, true, false, 1); }
         else if (L.outk == 2) { if (l0) FUSED_FAST(1, true, true, 2); else FUSED_FAST(1, true, false, 2); }
         else { if (l0) FUSED_FAST(1, true, true, 3); else FUSED_FAST(1, true, false, 3); }
@@ -1414,6 +1563,8 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
     j->lev_ev_used = 0;
     j->lev_bytes.clear();
     j->lev_hbm.clear();
+    j->pk_run = c->idwt_pk != 0;
+    j->pk_used = 0;
     const std::vector<LevelLaunch> &LL = fuse ? j->launches_fused : use_tile ? j->launches_tile : j->launches_generic;
     bool x3 = false;
     if (fuse && j->ll16_run && j->x3_ok && c->idwt_x3) {
@@ -1429,7 +1580,7 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
             hipLaunchKernelGGL(k_idwt_stream_ll16_x3, dim3(8 * ((total + 7) / 8)), dim3(256), lds, j->stream,
                                (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[0]), (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[1]),
                                (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[2]), (const uint32_t *)j->d_coef.p, buf_ptr(j, 1),
-                               th, nbands, j->x3_count, j->x3_lh[0], j->x3_lh[1], (int *)j->d_status.p + j->blocks.size(), c->ll16_test_bits);
+                               th, nbands, j->x3_count, j->x3_lh[0], j->x3_lh[1], (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
             hipEvent_t e1 = lev_event(j);
             if (e1) (void)hipEventRecord(e1, j->stream);
             j->lev_bytes.push_back(j->x3_alg);
@@ -1667,6 +1818,7 @@ extern "C" int htj2k_job_wait(htj2k_ctx *c, htj2k_job *j)
 }
 
 /* 0: the last run's LL bands were 32-bit, 1: 16-bit, 2: 16-bit, overflowed and run again with 32 (after htj2k_job_wait) */
+extern "C" int htj2k_job_idwt_packed(const htj2k_job *j) { return j ? j->pk_used : HTJ2K_ERR_EINVAL; }
 extern "C" int htj2k_job_ll16(const htj2k_job *j) { return j ? (j->ll16_run ? 1 : (j->ll16_fallbacks ? 2 : 0)) : HTJ2K_ERR_EINVAL; }
 
 extern "C" int htj2k_job_stage_ms(htj2k_ctx *c, htj2k_job *j, float *ms_ht, float *ms_idwt, float *ms_pack)

@@ -171,6 +171,12 @@ int  htj2k_job_ht_blocks_per_wave(const htj2k_job *job);
  * -- only crafted or corrupt coefficients do that -- and htj2k_job_wait / _download ran the transform again with
  * int32 LL bands before handing out the frames */
 int  htj2k_job_ll16(const htj2k_job *job);
+/* 0: no launch of the last run's final IDWT level ran on pairs of 16-bit samples; otherwise the number of bits the LL
+ * bands of the job had to fit for that (10..16; knob "idwt_pk").  The final 5/3 level of 8-bit pictures (rgb24 or 8-bit
+ * planes out, 16-bit sub-bands and LL band in) is computed with packed 16-bit instructions -- lifting, inverse RCT
+ * (jpeg2000dsp.c:78-91) and clip -- where the bands' M_b and the checked range of the LL band prove that no intermediate
+ * leaves 16 bits; the result is the reference's int32 arithmetic exactly. */
+int  htj2k_job_idwt_packed(const htj2k_job *job);
 int  htj2k_job_idwt_hbm_bytes(htj2k_ctx *ctx, htj2k_job *job, double *bytes, int cap);
 /* H2D: compressed codeblock bytes + descriptors (async on the job's stream) */
 int  htj2k_job_upload(htj2k_ctx *ctx, htj2k_job *job);
@@ -247,6 +253,8 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   "ht_pair"     1 (default): such jobs decode MagSgn with k_ht_decode_pair (two blocks per wave, a lane per quad)
  *   "idwt_x3"     1 (default): jobs with 16-bit LL bands run the first three 5/3 levels of every plane as one launch, the LL
  *                 bands in between in LDS (k_idwt_stream_ll16_x3); 0: one launch per level
+ *   "idwt_pk"     1 (default): final 5/3 levels of 8-bit pictures on pairs of 16-bit samples where that is exact
+ *                 (htj2k_job_idwt_packed); 0: 32-bit arithmetic throughout
  *   "ll16"        1 (default): such jobs also hold the LL bands between the IDWT levels as 16-bit samples, with a check
  *                 on the device and a second run with int32 LL bands should one not fit (htj2k_job_ll16)
  *   "device_gather"  1 (default): packets are uploaded as they are and the byte pool of the job is put together by
@@ -257,12 +265,16 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  * Environment variables (experiments and tests; read by htj2k_open unless noted):
  *   HTJ2K_HT=fused|split             "ht_mode" 0 | 1
  *   HTJ2K_IDWT=generic|tile|stream   "idwt_mode" 0 | 1 | 3
- *   HTJ2K_LL16=0|1, HTJ2K_FUSE=0|1   "ll16", "fuse_pack"
+ *   HTJ2K_LL16=0|1, HTJ2K_FUSE=0|1, HTJ2K_PK=0|1   "ll16", "fuse_pack", "idwt_pk"
  *   HTJ2K_MULTI_LDS=bytes            (per upload) most LDS a wave of k_ht_decode_multi may take for its blocks' MagSgn bits
  *                                    (default 12288): above it the job decodes one block per wave
  *   HTJ2K_STRIP=rows                 (per launch) rows per wave of the streaming IDWT kernels (default 8 or 16 by launch size)
  *   HTJ2K_TW16 / HTJ2K_TW32 / HTJ2K_TWF=columns   (per launch) output columns per wave of the streaming IDWT for 16-bit LL
  *                                    bands / 32-bit LL bands / the fused final level (64 .. 244; default 224 or 244 by row length)
+ *   HTJ2K_WPB=waves                  (first launch) waves per workgroup of the 16-bit streaming IDWT kernels, 1 .. 8 (default: the
+ *                                    strips of a row, at most 8)
+ *   HTJ2K_PK_LDS=bytes               (first launch) dynamic LDS the packed final-level kernel is launched with -- an occupancy limit,
+ *                                    the kernel uses none (default: two workgroups of eight waves per CU)
  *   HTJ2K_X3_TH=rows                 (per launch) rows of the third level one workgroup of k_idwt_stream_ll16_x3 reconstructs (default 24)
  *   HTJ2K_POISON=1                   fresh device buffers start as 0xA5 bytes (tools/gpu_random_configs.py) */
 int  htj2k_set_int(htj2k_ctx *ctx, const char *name, int value);

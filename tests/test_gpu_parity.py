@@ -601,6 +601,65 @@ def test_first_three_idwt_levels_in_one_launch(dec, orc):
         os.environ.pop("HTJ2K_X3_TH", None)
 
 
+def test_final_level_on_pairs_of_16_bit_samples(dec, orc):
+    """knob "idwt_pk" (default on): the final 5/3 level of 8-bit pictures -- lifting, inverse RCT, clip, rgb24 / 8-bit plane
+    store -- runs on pairs of 16-bit samples (v_pk_* instructions) where interval arithmetic over the bands' M_b and the
+    checked range of the LL band shows that no intermediate can leave 16 bits.  Same frames as with 32-bit arithmetic, as
+    the oracle and as the source: RGB with and without the RCT, gray, 4:2:0 planes, one level (the LL band is the block
+    decoder's, unchecked) up to five, line ends inside a wave (mirror lanes), several frames per job; deeper pictures do
+    not qualify; and with the tightened range check firing the job falls back to the 32-bit kernels."""
+    cases = [(256, 192, 3, 1, 1), (512, 256, 3, 1, 5), (1920, 1080, 3, 1, 5), (1024, 542, 1, 0, 5), (256, 46, 1, 0, 2), (512, 258, 3, 0, 3),
+             (64, 64, 3, 1, 1), (3840, 2160, 3, 1, 5)]
+    try:
+        for (w, h, nc, mct, nl) in cases:
+            img = vecgen.synth_image(w, h, nc, seed=w + h + nl, noise=10)
+            data = vecgen.encode(img, mct=mct, nlevels=nl)
+            info_o, planes_o, _ = orc.decode(data)
+            for pk in (1, 0):
+                dec.set_int("idwt_pk", pk)
+                job = dec.job().parse_batch([data, data]).upload().run().wait()
+                assert job.coef16() and job.block_errors() == 0, (w, h, pk)
+                used = job.idwt_packed()
+                assert (10 <= used <= 16) if pk else used == 0, (w, h, nc, mct, nl, pk, used)
+                for f in range(2):
+                    assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(f)[1], planes_o)), (w, h, nc, mct, nl, pk, f)
+                job.free()
+            if nc == 3:
+                dec.set_int("idwt_pk", 1)
+                info, planes, _, st = dec.decode(data)
+                assert np.array_equal(planes[0].reshape(h, w, 3), np.stack(img, -1))
+        dec.set_int("idwt_pk", 1)
+        # 4:2:0: three single-plane groups of two sizes
+        img = vecgen.synth_image(1024, 512, 3, seed=12, dx=[1, 2, 2], dy=[1, 2, 2])
+        data = vecgen.encode(img, nlevels=4, dx=[1, 2, 2], dy=[1, 2, 2], width=1024, height=512)
+        info_o, planes_o, _ = orc.decode(data)
+        job = dec.job().parse_batch([data, data]).upload().run().wait()
+        assert job.idwt_packed() >= 10
+        for f in range(2):
+            assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(f)[1], planes_o)), ("420", f)
+        job.free()
+        # 10-bit components: 16-bit sub-bands, but not this kernel
+        img = vecgen.synth_image(512, 256, 3, depth=10, seed=3, noise=10)
+        data = vecgen.encode(img, mct=1, nlevels=4, depth=10)
+        info_o, planes_o, _ = orc.decode(data)
+        job = dec.job().parse_batch([data]).upload().run().wait()
+        assert job.coef16() and job.idwt_packed() == 0
+        assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(0)[1], planes_o))
+        job.free()
+        # the LL bands are checked against the bits the packed kernel needs, and a job that fails runs again in 32 bits
+        img = vecgen.synth_image(512, 256, 3, seed=5, noise=10)
+        data = vecgen.encode(img, mct=1, nlevels=5)
+        info_o, planes_o, _ = orc.decode(data)
+        dec.set_int("ll16_test_bits", 6)
+        job = dec.job().parse_batch([data]).upload().run().wait()
+        assert job.ll16() == 2 and job.idwt_packed() == 0
+        assert all(np.array_equal(a, d) for a, d in zip(job.download_frame(0)[1], planes_o))
+        job.free()
+    finally:
+        dec.set_int("idwt_pk", 1)
+        dec.set_int("ll16_test_bits", 16)
+
+
 def test_ll16_overflow_runs_the_transform_again(dec, orc):
     """Nothing bounds the LL bands of crafted or corrupt coefficient data, so the level kernels flag a sample that does
     not fit and the job repeats the IDWT with int32 LL bands before it hands out frames.  A stream produced by a forward
