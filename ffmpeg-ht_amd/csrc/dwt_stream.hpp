@@ -278,11 +278,30 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                     const uint16_t *lrow = (const uint16_t *)ll_base + A[c].ll_off + (size_t)(iy[0] - ll_row0) * A[c].ll_stride;
                     Lr[c][0] = *(const uint32_t *)(lrow + col[0]);
                 } else {
-                    const uint2 le = *(const uint2 *)(llp[c] + (size_t)iy[0] * A[c].ll_stride + col[0]);
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(1))) const u32x2 g_cu2;
+                    g_cchar *lrow = sgpr_ptr(llp[c] + (size_t)iy[0] * A[c].ll_stride);
+                    uint32_t cl = (uint32_t)col[0] * 4u;
+                    asm volatile("" : "+v"(cl));
+                    const u32x2 le = *(g_cu2 *)(lrow + cl);
                     Lr[c][0] = le.x; Lr[c][2] = le.y;
                 }
             }
-        } else if (FAST || interior) {
+        } else if (FAST) {                                     /* (as above: scalar row bases, 32-bit lane offsets) */
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(1))) const u32x2 g_cu2;
+                g_cchar *lrow = sgpr_ptr(llp[c] + (size_t)iy[0] * A[c].ll_stride);
+                g_cchar *brow0 = sgpr_ptr(bandp[c] + (size_t)iy[0] * A[c].g.stride), *brow1 = sgpr_ptr(bandp[c] + (size_t)iy[1] * A[c].g.stride);
+                uint32_t cb0 = (uint32_t)col[0] * 4u, cb1 = (uint32_t)col[1] * 4u;
+                asm volatile("" : "+v"(cb0), "+v"(cb1));
+                const u32x2 le = *(g_cu2 *)(lrow + cb0), lo = *(g_cu2 *)(brow0 + cb1);
+                const u32x2 he = *(g_cu2 *)(brow1 + cb0), ho = *(g_cu2 *)(brow1 + cb1);
+                Lr[c][0] = le.x; Lr[c][1] = lo.x; Lr[c][2] = le.y; Lr[c][3] = lo.y;
+                Hr[c][0] = he.x; Hr[c][1] = ho.x; Hr[c][2] = he.y; Hr[c][3] = ho.y;
+            }
+        } else if (interior) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const uint32_t *lrow = llp[c] + (size_t)iy[0] * A[c].ll_stride;
@@ -745,8 +764,9 @@ __device__ __forceinline__ bool stream_strip(const StreamGrid &G, int &bx, int &
 }
 
 /* plain level: one DwtTileArgs table entry per plane, blockDim = one wave */
+/* FASTONLY kernels may be launched with up to eight waves per workgroup (stream_strip) */
 template <int TYPE, bool FASTONLY, bool C16 = false, bool LL16 = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(FASTONLY ? 512 : 64)
 k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
               const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G)
 {
@@ -842,7 +862,7 @@ k_idwt_stream_ll16_x3(const DwtTileArgs *__restrict__ args0, const DwtTileArgs *
 
 /* final level + inverse MCT + frame store: one DwtFusedArgs table entry per component group */
 template <int TYPE, int NC, bool FASTONLY, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
-__global__ void __launch_bounds__(C16 ? 512 : 64)
+__global__ void __launch_bounds__(FASTONLY && TYPE != J2K_DWT97_INT ? 512 : 64)       /* (9/7 fixed point, three components: 232-280 VGPRs) */
 k_idwt_stream_pack(const DwtFusedArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, const PackTile *__restrict__ tiles, int th, StreamGrid G)
 {

@@ -1451,7 +1451,7 @@ static StreamGrid stream_grid(int max_lh, int max_lv, int th, int count, int tw 
  * the 16 strips of a row, 718 / 724; 16 waves 700-707; level 4 250 -> 238-243 us. */
 static int stream_wpb(int max_lh, int tw)
 {
-    static const int e = getenv("HTJ2K_WPB") ? atoi(getenv("HTJ2K_WPB")) : 0;
+    const int e = getenv("HTJ2K_WPB") ? atoi(getenv("HTJ2K_WPB")) : 0;      /* (per launch: tools/gpu_idwt_ab.py flips it between runs) */
     if (e >= 1 && e <= 8) return e;
     return std::max(1, std::min(8, (max_lh + tw - 1) / tw));
 }
@@ -1459,9 +1459,15 @@ static int stream_wpb(int max_lh, int tw)
  * kernel needs 61 VGPRs and would run 8 waves per SIMD, and with that many strips in flight the memory system does worse:
  * C2 final level, one wave per workgroup, 792 us at 32 waves per CU, 754 at 20, 732 at 16, 718 at 12, 757 at 8; workgroups
  * of eight waves 713 us at three per CU, 660-683 at two, 739 at one. */
+/* experiments: dynamic LDS (bytes per wave) for the other multi-wave streaming launches, as an occupancy limit */
+static int stream_occ_lds(int wpb)
+{
+    const int e = getenv("HTJ2K_OCC_LDS") ? atoi(getenv("HTJ2K_OCC_LDS")) : 0;
+    return std::min(e * wpb, 48 * 1024);
+}
 static int stream_pk_lds(int wpb)
 {
-    static const int e = getenv("HTJ2K_PK_LDS") ? atoi(getenv("HTJ2K_PK_LDS")) : -1;
+    const int e = getenv("HTJ2K_PK_LDS") ? atoi(getenv("HTJ2K_PK_LDS")) : -1;
     if (e >= 0) return e;
     const int per_cu = wpb >= 8 ? 2 : wpb >= 4 ? 3 : 12 / wpb;          /* workgroups */
     return (160 * 1024 / per_cu) & ~1023;
@@ -1473,11 +1479,14 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
 {
     if (mode >= 3 && min_l >= 2) {
         const int th = stream_strip_rows(max_lh, max_lv, count);
-        const StreamGrid G = stream_grid(max_lh, max_lv, th, count, stream_strip_cols(max_lh, all_fast ? 4 : 0));
-        dim3 g(8 * G.per_xcd);
-        if (TYPE == J2K_DWT53 && coef16 == 2) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
-        else if (TYPE == J2K_DWT53 && coef16 == 1) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
-        else if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        const int tw = stream_strip_cols(max_lh, all_fast ? 4 : 0);
+        const int wpb = all_fast || (TYPE == J2K_DWT53 && coef16) ? stream_wpb(max_lh, tw) : 1;
+        const StreamGrid G = stream_grid(max_lh, max_lv, th, count, tw, wpb);
+        const dim3 g(8 * G.per_xcd / wpb), blk(64 * wpb);
+        const int lds = stream_occ_lds(wpb);
+        if (TYPE == J2K_DWT53 && coef16 == 2) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, true>), g, blk, lds, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        else if (TYPE == J2K_DWT53 && coef16 == 1) hipLaunchKernelGGL((k_idwt_stream<J2K_DWT53, true, true, false>), g, blk, lds, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
+        else if (all_fast) hipLaunchKernelGGL((k_idwt_stream<TYPE, true>), g, blk, lds, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
         else hipLaunchKernelGGL((k_idwt_stream<TYPE, false>), g, dim3(64), 0, s, (const DwtTileArgs *)tab, ll, band, out, th, G);
     } else {
         dim3 g((max_lh + TILE_W - 1) / TILE_W, (max_lv + TILE_H - 1) / TILE_H, count);
@@ -1513,14 +1522,16 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
 {
     const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
     const int tw = stream_strip_cols(L.max_lh, L.outk == 0 ? 3 : L.outk == 1 ? 6 : L.outk == 2 ? 1 : L.outk == 3 ? 2 : 0);
-    const int wpb = TYPE == J2K_DWT53 && j->coef_is16 ? stream_wpb(L.max_lh, tw) : 1;
+    const bool multi = (TYPE == J2K_DWT53 && j->coef_is16) || (TYPE != J2K_DWT97_INT && (L.outk >= 1 || (L.nc == 3 && L.all_fast)));   /* FASTONLY kernels */
+    const int wpb = multi ? stream_wpb(L.max_lh, tw) : 1;
+    const int occ_lds = stream_occ_lds(wpb);
     const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, tw, wpb);
     dim3 g(8 * G.per_xcd / wpb);
     const dim3 blk(64 * wpb);
     const DwtFusedArgs *tab = (const DwtFusedArgs *)((uint8_t *)j->d_desc.p + L.table_off);
     const PackTile *tiles = (const PackTile *)((uint8_t *)j->d_desc.p + j->pack_off);
     const uint32_t *band = (const uint32_t *)j->d_coef.p;
-#define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, (C16_) ? blk : dim3(64), 0, j->stream, tab, ll, band, tiles, th, G)
+#define FUSED_FAST(NC_, C16_, LL16_, K_) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE == J2K_DWT97_INT && (K_) ? J2K_DWT53 : TYPE, NC_, true, C16_, LL16_, K_>), g, blk, occ_lds, j->stream, tab, ll, band, tiles, th, G)
     if (TYPE == J2K_DWT53 && j->coef_is16) {             /* coef16_ok: every fused launch is a fast-store one */
         const bool l0 = L.level == 0 || j->ll16_run;      /* the LL band is 16-bit: the block decoder's, or the level below wrote it so */
         const bool pk = l0 && L.pk_bits && j->pk_run;   /* pairs of 16-bit samples all the way (pk16_eligibility) */
@@ -1543,7 +1554,7 @@ static void launch_fused_level(htj2k_job *j, const LevelLaunch &L, const uint32_
     else if (L.outk == 2) FUSED_FAST(1, false, false, 2);
     else if (L.outk == 3) FUSED_FAST(1, false, false, 3);
     else if (L.nc == 1) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 1, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
-    else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
+    else if (L.nc == 3 && L.all_fast) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, true>), g, blk, occ_lds, j->stream, tab, ll, band, tiles, th, G);
     else if (L.nc == 3) hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 3, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
     else hipLaunchKernelGGL((k_idwt_stream_pack<TYPE, 4, false>), g, dim3(64), 0, j->stream, tab, ll, band, tiles, th, G);
 }
