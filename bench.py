@@ -353,7 +353,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=48, help="4K frames per step and per GPU (16 GB of HBM at 48; the rate is flat from 16: 66 -> 69 Gpixel/s)")
+    ap.add_argument("--batch", type=int, default=128, help="4K frames per step and per GPU (about 48 GB of HBM at 128 with the one-job copy of the roofline pass; "
+                    "measured on one box, two jobs: 48 frames 148, 64 156, 96 162, 128 167 Gpixel/s -- the block decoder's launches balance "
+                    "better over the SIMDs the more waves they have; the IDWT does not care)")
     ap.add_argument("--jobs", type=int, default=2, help="the batch is split over this many jobs on HIP streams of their own, as the "
                     "frame pipeline keeps several jobs in flight: the instruction-bound HT kernels of one job run beside the "
                     "bandwidth-bound IDWT launches of the other.  `roofline` always comes from a separate pass of ONE job "

@@ -178,8 +178,8 @@ struct DwtFusedArgs {
  * element offsets, the buffer read as int16_t), and *ovf is set when a sample does not fit: an LL band of a real
  * picture stays in the picture's range, but nothing bounds what crafted or corrupt coefficients add up to.  The host
  * then runs the transform again with 32-bit LL bands (htj2k_device.hip, job_settle). */
-/* PK (FAST && FUSED, 16-bit sub-bands and LL band, 8-bit output of 8-bit components: OUTK 0 or 2): the whole step on pairs of
- * 16-bit samples, see stream_hlift_pk */
+/* PK (FAST, 16-bit sub-bands and LL band; a plain level that stores a 16-bit LL band, or the fused final level with 8-bit
+ * output of 8-bit components, OUTK 0 or 2): the whole step on pairs of 16-bit samples, see stream_hlift_pk */
 template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
@@ -189,7 +189,8 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
     /* ll_row0 / out_row0 (FAST 16-bit paths only): the LL input / the output is a window whose first row is row ll_row0 /
      * out_row0 of the band (k_idwt_stream_ll16_x3's LDS windows) */
     using O = LiftOps<TYPE>;
-    static_assert(!PK || (TYPE == J2K_DWT53 && FUSED && FAST && C16 && LL16 && (OUTK == 0 || OUTK == 2)), "PK: the 8-bit fused fast stores of 16-bit jobs");
+    static_assert(!PK || (TYPE == J2K_DWT53 && FAST && C16 && LL16 && (FUSED ? (OUTK == 0 || OUTK == 2) : OUTK == 16)),
+                  "PK: 16-bit levels of 16-bit jobs and their 8-bit fused fast stores");
     constexpr int HALO = O::HALO, DELAY = O::DELAY;
     const DwtLevel g = A[0].g;
     /* the strip: columns [bx tw, bx tw + tw), rows [by th, by th + th) -- or, for callers that cut a level their own way
@@ -383,7 +384,20 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
 #pragma unroll
                     for (int k = 0; k < 4; k++) val[c][k] = (uint32_t)((int32_t)((int32_t)val[c][k] + 128) >> 8);   /* :534-536 */
             }
-            if (!FUSED && OUTK == 16) {
+            if (!FUSED && OUTK == 16 && PK) {
+                /* val[c][0] = (x0, x2), val[c][1] = (x1, x3): two byte permutes put them in order; x + hb has no bit at or above
+                 * ovf_bits in either half exactly when both fit ovf_bits bits */
+                const uint32_t hb2 = (1u << (ovf_bits - 1)) * 0x10001u, hm2 = ((0xFFFFu << ovf_bits) & 0xFFFFu) * 0x10001u;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    uint16_t *p = (uint16_t *)out_base + A[c].out_off + (size_t)(y - out_row0) * A[c].out_stride + xa;
+                    const uint32_t t = pk_bits(pk_from(val[c][0]) + pk_from(hb2)) | pk_bits(pk_from(val[c][1]) + pk_from(hb2));
+                    if (lane_ok) {
+                        ovf_acc |= t & hm2;
+                        *(uint2 *)p = make_uint2(__builtin_amdgcn_perm(val[c][1], val[c][0], 0x05040100), __builtin_amdgcn_perm(val[c][1], val[c][0], 0x07060302));
+                    }
+                }
+            } else if (!FUSED && OUTK == 16) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     uint16_t *p = (uint16_t *)out_base + A[c].out_off + (size_t)(y - out_row0) * A[c].out_stride + xa;
@@ -777,6 +791,7 @@ k_idwt_stream(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__
 }
 
 /* plain 5/3 level of a job with 16-bit sub-bands whose LL bands are 16-bit as well, in and out */
+template <bool PK>
 __global__ void __launch_bounds__(512)
 k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restrict__ ll_base,
                    const uint32_t *__restrict__ band_base, uint32_t *__restrict__ out_base, int th, StreamGrid G,
@@ -785,7 +800,7 @@ k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restr
     int bx, by, bz;
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
-    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
+    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16, PK>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
 }
 
 /* ================================================================== three levels in one launch
@@ -816,6 +831,7 @@ __host__ __device__ inline X3Rows x3_rows(int r0, int r1, int lv0, int lv1)
 __host__ __device__ inline int x3_win0_rows(int th) { return th / 4 + 6; }
 __host__ __device__ inline int x3_win1_rows(int th) { return th / 2 + 5; }
 
+template <bool PK>
 __global__ void __launch_bounds__(256)
 k_idwt_stream_ll16_x3(const DwtTileArgs *__restrict__ args0, const DwtTileArgs *__restrict__ args1, const DwtTileArgs *__restrict__ args2,
                       const uint32_t *__restrict__ coef, uint32_t *__restrict__ out_base, int th, int nbands, int nplanes, int max_lh0, int max_lh1,
@@ -850,7 +866,7 @@ k_idwt_stream_ll16_x3(const DwtTileArgs *__restrict__ args0, const DwtTileArgs *
         for (int i = wv; i < ncol * nrow; i += 4) {
             const int bx = i % ncol, pr = i / ncol;
             const int y0 = lo + pr * part, rows = min(part, lo + n - y0);
-            idwt_stream_impl<J2K_DWT53, 1, false, true, true, LL16, 16>(A, ll, coef, out, nullptr, 0, rows, TW, bx, 0, ovf, ovf_bits, y0, 1, ll_row0, out_row0);
+            idwt_stream_impl<J2K_DWT53, 1, false, true, true, LL16, 16, PK>(A, ll, coef, out, nullptr, 0, rows, TW, bx, 0, ovf, ovf_bits, y0, 1, ll_row0, out_row0);
         }
     };
     level(A0, coef, out0, R.lo0, R.n0, 0, R.lo0);

@@ -835,8 +835,7 @@ static void pk16_eligibility(htj2k_job *j)
     for (LevelLaunch &L : j->launches_fused) L.pk_bits = 0;
     if (!j->coef16_ok) return;
     const int ntc = (int)j->tilecomps.size();
-    /* the largest M_b among the blocks of each quadrant of every plane's final level: 0 the LL quadrant (the LL band itself
-     * when the plane has one level), 1 HL, 2 LH, 3 HH */
+    /* the largest M_b among the blocks of every band: [plane][level][0 LL (level 0 only), 1 HL, 2 LH, 3 HH] */
     std::vector<std::pair<uint32_t, int>> start(ntc);
     for (int t = 0; t < ntc; t++) start[t] = { j->tilecomps[t].plane_off, t };
     std::sort(start.begin(), start.end());
@@ -844,47 +843,72 @@ static void pk16_eligibility(htj2k_job *j)
         auto it = std::upper_bound(start.begin(), start.end(), std::make_pair(off, 1 << 30));
         return it == start.begin() ? -1 : (it - 1)->second;
     };
-    std::vector<uint8_t> mb((size_t)ntc * 4, 0);
+    std::vector<uint8_t> mb((size_t)ntc * J2K_MAX_DWTLEV * 4, 0);
     for (const J2kBlock &b : j->blocks) {
         const int t = plane_of(b.plane_off);
         if (t < 0) return;
         const J2kTileComp &tc = j->tilecomps[t];
-        const int lev = tc.ndeclevels - 1;
-        if (lev < 0 || tc.w <= 0) return;
+        if (tc.ndeclevels < 1 || tc.ndeclevels > J2K_MAX_DWTLEV || tc.w <= 0) return;
         const uint32_t off = b.plane_off - tc.plane_off;
         const int x = (int)(off % (uint32_t)tc.w), y = (int)(off / (uint32_t)tc.w);
-        const int mh = tc.mod[lev][0], mv = tc.mod[lev][1];
-        const int nlx = ((mh + tc.linelen[lev][0] + 1) >> 1) - ((mh + 1) >> 1), nly = ((mv + tc.linelen[lev][1] + 1) >> 1) - ((mv + 1) >> 1);
-        uint8_t &m = mb[(size_t)t * 4 + (x >= nlx ? 1 : 0) + (y >= nly ? 2 : 0)];
+        int lev = tc.ndeclevels - 1, band = 0;
+        for (; lev >= 0; lev--) {                           /* the outermost level whose low-pass quadrant does not hold the block */
+            const int mh = tc.mod[lev][0], mv = tc.mod[lev][1];
+            const int nlx = ((mh + tc.linelen[lev][0] + 1) >> 1) - ((mh + 1) >> 1), nly = ((mv + tc.linelen[lev][1] + 1) >> 1) - ((mv + 1) >> 1);
+            band = (x >= nlx ? 1 : 0) + (y >= nly ? 2 : 0);
+            if (band || lev == 0) break;
+        }
+        uint8_t &m = mb[((size_t)t * J2K_MAX_DWTLEV + lev) * 4 + band];
         if (b.M_b > m) m = b.M_b;
     }
+    /* the most bits (16 .. 10 for 8-bit components) of LL input with which plane t's
+     * level lev stays inside 16 bits: 0 = none; level 0 reads the block decoder's LL band, bounded by its own M_b and unchecked */
+    auto bounds_of = [&](int t, int lev, int k, long (&B)[4]) {
+        const uint8_t *m = &mb[((size_t)t * J2K_MAX_DWTLEV + lev) * 4];
+        B[0] = lev == 0 ? (1L << m[0]) - 1 : 1L << (k - 1);
+        for (int q = 1; q < 4; q++) B[q] = (1L << m[q]) - 1;
+    };
     int job_bits = 16;
     for (LevelLaunch &L : j->launches_fused) {
-        if (L.nc == 0 || L.type != J2K_DWT53 || !(L.outk == 0 || L.outk == 2)) continue;
-        const DwtFusedArgs *fa = (const DwtFusedArgs *)(j->h_desc.data() + L.table_off);
+        if (L.type != J2K_DWT53) continue;
         int bits = 16;
-        for (int i = 0; i < L.count && bits; i++) {
-            const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + fa[i].pack_tile;
-            const bool rct = L.outk == 0 && PT->mct != 0;
-            int tcs[3];
-            bool ok = PT->precision == 8;
-            for (int cc = 0; cc < L.nc && ok; cc++) {
-                tcs[cc] = plane_of(fa[i].a[cc].g.plane_off);
-                ok = tcs[cc] >= 0 && j->tilecomps[tcs[cc]].plane_off == fa[i].a[cc].g.plane_off && PT->c[L.outk == 2 ? fa[i].comp0 : cc].cbps == 8;
-            }
-            int k = 0;
-            for (k = ok ? bits : 0; k >= 10; k--) {           /* below 10 bits the LL band of an ordinary 8-bit picture may not fit */
-                long B[3][4];
-                for (int cc = 0; cc < L.nc; cc++) {
-                    const uint8_t *m = &mb[(size_t)tcs[cc] * 4];
-                    /* one level: the LL band is the block decoder's, bounded by its own M_b, and nothing checks it */
-                    B[cc][0] = L.level == 0 ? (1L << m[0]) - 1 : 1L << (k - 1);
-                    for (int q = 1; q < 4; q++) B[cc][q] = (1L << m[q]) - 1;
+        if (L.nc == 0) {                                    /* plain level: its output is checked, its input has to be bounded */
+            const DwtTileArgs *ta = (const DwtTileArgs *)(j->h_desc.data() + L.table_off);
+            for (int i = 0; i < L.count && bits; i++) {
+                const int t = plane_of(ta[i].g.plane_off);
+                int k = t >= 0 && j->tilecomps[t].plane_off == ta[i].g.plane_off ? bits : 0;
+                /* (a component of n bits has LL bands of n + 1 bits with the RCT, and the check must leave an ordinary picture
+                 * alone: twice that range at least) */
+                const int kmin = k ? j->tilecomps[t].cbps + 2 : 0;
+                for (; k >= kmin && k; k--) {
+                    long B[4];
+                    bounds_of(t, L.level, k, B);
+                    if (pk16_lift_bound(B[0], B[1], B[2], B[3]) >= 0) break;
+                    if (L.level == 0) { k = 0; break; }
                 }
-                if (pk16_bounds(B, L.nc, rct)) break;
-                if (L.level == 0) { k = 0; break; }
+                bits = k >= kmin ? k : 0;
             }
-            bits = k >= 10 ? k : 0;
+        } else {
+            if (!(L.outk == 0 || L.outk == 2)) continue;
+            const DwtFusedArgs *fa = (const DwtFusedArgs *)(j->h_desc.data() + L.table_off);
+            for (int i = 0; i < L.count && bits; i++) {
+                const PackTile *PT = (const PackTile *)(j->h_desc.data() + j->pack_off) + fa[i].pack_tile;
+                const bool rct = L.outk == 0 && PT->mct != 0;
+                int tcs[3];
+                bool ok = PT->precision == 8;
+                for (int cc = 0; cc < L.nc && ok; cc++) {
+                    tcs[cc] = plane_of(fa[i].a[cc].g.plane_off);
+                    ok = tcs[cc] >= 0 && j->tilecomps[tcs[cc]].plane_off == fa[i].a[cc].g.plane_off && PT->c[L.outk == 2 ? fa[i].comp0 : cc].cbps == 8;
+                }
+                int k = ok ? bits : 0;
+                for (; k >= 10; k--) {
+                    long B[3][4];
+                    for (int cc = 0; cc < L.nc; cc++) bounds_of(tcs[cc], L.level, k, B[cc]);
+                    if (pk16_bounds(B, L.nc, rct)) break;
+                    if (L.level == 0) { k = 0; break; }
+                }
+                bits = k >= 10 ? k : 0;
+            }
         }
         L.pk_bits = bits;
         if (bits && L.level > 0) job_bits = std::min(job_bits, bits);
@@ -1507,9 +1531,14 @@ static void launch_tile_level(htj2k_ctx *c, htj2k_job *j, const LevelLaunch &L, 
         const int th = stream_strip_rows(L.max_lh, L.max_lv, L.count);
         const int tw = stream_strip_cols(L.max_lh, 2), wpb = stream_wpb(L.max_lh, tw);
         const StreamGrid G = stream_grid(L.max_lh, L.max_lv, th, L.count, tw, wpb);
-        hipLaunchKernelGGL(k_idwt_stream_ll16, dim3(8 * G.per_xcd / wpb), dim3(64 * wpb), 0, j->stream,
-                           (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
-                           (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
+        if (L.pk_bits && j->pk_run)
+            hipLaunchKernelGGL(k_idwt_stream_ll16<true>, dim3(8 * G.per_xcd / wpb), dim3(64 * wpb), 0, j->stream,
+                               (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
+                               (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
+        else
+            hipLaunchKernelGGL(k_idwt_stream_ll16<false>, dim3(8 * G.per_xcd / wpb), dim3(64 * wpb), 0, j->stream,
+                               (const DwtTileArgs *)((uint8_t *)j->d_desc.p + L.table_off), ll, (const uint32_t *)j->d_coef.p, out, th, G,
+                               (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
         return;
     }
     launch_tile_generic<TYPE>((uint8_t *)j->d_desc.p + L.table_off, L.max_lh, L.max_lv, L.min_l, L.count, c->idwt_mode,
@@ -1586,9 +1615,13 @@ static int run_idwt(htj2k_ctx *c, htj2k_job *j, bool use_tile, bool fuse)
             const int nbands = (j->x3_lv2 + th - 1) / th, total = nbands * j->x3_count;
             hipEvent_t e0 = lev_event(j);
             if (e0) (void)hipEventRecord(e0, j->stream);
+            bool x3pk = j->pk_run;                            /* all three levels on pairs of 16-bit samples, or none */
+            for (const LevelLaunch &L : LL)
+                if (L.type == J2K_DWT53 && L.nc == 0 && L.level < 3 && !L.pk_bits) x3pk = false;
+            auto kern = x3pk ? k_idwt_stream_ll16_x3<true> : k_idwt_stream_ll16_x3<false>;
             if (lds > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)k_idwt_stream_ll16_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_idwt_stream_ll16_x3, dim3(8 * ((total + 7) / 8)), dim3(256), lds, j->stream,
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, j->stream,
                                (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[0]), (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[1]),
                                (const DwtTileArgs *)((uint8_t *)j->d_desc.p + j->x3_tab[2]), (const uint32_t *)j->d_coef.p, buf_ptr(j, 1),
                                th, nbands, j->x3_count, j->x3_lh[0], j->x3_lh[1], (int *)j->d_status.p + j->blocks.size(), ll16_check_bits(c, j));
