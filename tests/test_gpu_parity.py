@@ -841,6 +841,21 @@ def test_full_size_4k_properties(dec, orc):
     assert np.array_equal(got, np.stack(img, -1))
     info_o, planes_o, _ = orc.decode(data)
     assert oracle.framecrc(planes) == oracle.framecrc(planes_o)
+    # single-frame calls on packets of this size stage and upload the packet in pieces on helper threads while the caller's
+    # copy is parsed: other frames through the same buffers, a packet that is cut short (the parser's error, no hang), then
+    # the first frame again
+    img2 = vecgen.synth_image(3840, 2160, 3, seed=9, noise=3)
+    data2 = vecgen.encode(img2, mct=1)
+    for d, im in ((data2, img2), (data, img), (data2, img2)):
+        info, planes, _, st = dec.decode(d)
+        assert st.n_block_errors == 0 and np.array_equal(planes[0].reshape(2160, 3840, 3), np.stack(im, -1))
+    import ffmpeg_ht_amd as m
+    try:
+        dec.decode(data[:len(data) // 2])
+    except m.Htj2kError:
+        pass
+    info, planes, _, st = dec.decode(data)
+    assert np.array_equal(planes[0].reshape(2160, 3840, 3), np.stack(img, -1))
 
 
 def test_full_size_4k_422_irreversible(dec, orc):
