@@ -76,7 +76,7 @@ EXPORTS = ["htj2k_open", "htj2k_close", "htj2k_set_log", "htj2k_probe", "htj2k_d
            "htj2k_idwt_bench", "htj2k_copy_bench", "htj2k_mct_planes", "htj2k_ht_blocks", "htj2k_mq_blocks", "htj2k_job_block_errors",
            "htj2k_job_num_blocks", "htj2k_job_device_plane", "htj2k_set_int", "htj2k_version", "htj2k_device_name",
            "htj2k_job_parse_batch", "htj2k_job_parse_batch_ex", "htj2k_job_num_frames", "htj2k_job_host_ms", "htj2k_job_frame_info", "htj2k_job_download_frame",
-           "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16", "htj2k_job_idwt_packed", "htj2k_job_ht_blocks_per_wave",
+           "htj2k_job_idwt_launches", "htj2k_job_idwt_hbm_bytes", "htj2k_job_coef16", "htj2k_job_ll16", "htj2k_job_idwt_packed", "htj2k_pk16_lift_bound", "htj2k_pk16_bounds", "htj2k_job_ht_blocks_per_wave",
            "htj2k_pipe_open", "htj2k_pipe_send", "htj2k_pipe_send_ref", "htj2k_pipe_flush", "htj2k_pipe_info", "htj2k_pipe_receive",
            "htj2k_pipe_skip", "htj2k_pipe_close", "htj2k_host_alloc", "htj2k_host_free",
            "htj2k_pipe_receive_device", "htj2k_pipe_receive_device_ref", "htj2k_pipe_release_device", "htj2k_job_device_frame", "htj2k_device_to_host",

@@ -874,6 +874,9 @@ static bool pk16_bounds(const long (*B)[4], int nc, bool rct)     /* B[c] = { LL
     return true;
 }
 
+extern "C" long htj2k_pk16_lift_bound(long ll, long hl, long lh, long hh) { return pk16_lift_bound(ll, hl, lh, hh); }
+extern "C" int htj2k_pk16_bounds(const long (*b)[4], int nc, int rct) { return b && nc >= 1 && nc <= 3 && pk16_bounds(b, nc, rct != 0) ? 1 : 0; }
+
 static void pk16_eligibility(htj2k_job *j)
 {
     j->pk_bits = 0;

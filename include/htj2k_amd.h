@@ -212,6 +212,14 @@ int  htj2k_idwt_bench(htj2k_ctx *ctx, int w, int h, int decomp_levels, int type,
  * copies `mbytes` MB of device memory per launch (16-byte elements, grid-stride; best of three launch shapes) on the
  * context's device -- the ceiling a bandwidth-bound kernel can be held against on this particular box */
 int  htj2k_copy_bench(htj2k_ctx *ctx, int mbytes, int iters, float *gbps);
+/* The host-side proof behind knob "idwt_pk" (no GPU needed; tests/test_pk16_bounds.py checks it against a simulation
+ * of the kernel's wrapping 16-bit arithmetic): with |LL| <= ll, |HL| <= hl, |LH| <= lh, |HH| <= hh on one level of the
+ * inverse 5/3 transform (jpeg2000dwt.c:309-385), the largest magnitude any output sample can have, or -1 when some
+ * intermediate sum of the horizontal or vertical lifting could leave 16 bits. */
+long htj2k_pk16_lift_bound(long ll, long hl, long lh, long hh);
+/* ... and for a group of `nc` components, b[c] = { ll, hl, lh, hh }, followed by the inverse RCT when `rct` != 0
+ * (jpeg2000dsp.c:78-91; the two final sums of the RCT saturate and are not bounded): 1 = exact in 16 bits, 0 = not */
+int  htj2k_pk16_bounds(const long (*b)[4], int nc, int rct);
 /* Jpeg2000DSPContext.mct_decode[type] (jpeg2000dsp.c:43-91) on host planes */
 int  htj2k_mct_planes(htj2k_ctx *ctx, void *p0, void *p1, void *p2, int csize, int type);
 
