@@ -34,14 +34,23 @@ MODE = os.environ.get("MODE", "follow")     # follow: as bench.py (the host read
 # job 1, so that the IDWT of one always runs beside the block decoder of the other -- 162.3 Gpixel/s against 165.9 with both
 # jobs in step: the kernel timeline shows the jobs of this pass running the same stage side by side, and that is the better
 # arrangement -- two latency-bound k_ht_vlc2 launches fill each other's issue gaps.)
+import threading
 def timed():
     for job in jobs: job.run(7)
     for job in jobs: job.wait()
     t0 = time.perf_counter()
-    for _ in range(STEPS):
-        for job in jobs: job.run(7)
-        if MODE == "follow":
-            for job in jobs: job.stage_ms()
+    if MODE == "threads":                   # a host thread per job, as htj2k_pipe's workers: run, wait for the step, run again
+        def work(job):
+            for _ in range(STEPS):
+                job.run(7); job.stage_ms()
+        th = [threading.Thread(target=work, args=(job,)) for job in jobs]
+        for t in th: t.start()
+        for t in th: t.join()
+    else:
+        for _ in range(STEPS):
+            for job in jobs: job.run(7)
+            if MODE == "follow":
+                for job in jobs: job.stage_ms()
     for job in jobs: job.wait()
     return STEPS * (BATCH // JOBS) * JOBS * W * H / (time.perf_counter() - t0) / 1e9
 
