@@ -660,6 +660,30 @@ def test_final_level_on_pairs_of_16_bit_samples(dec, orc):
         dec.set_int("ll16_test_bits", 16)
 
 
+def test_packed_range_check_leaves_extreme_pictures_alone(dec):
+    """The packed final level asks the LL bands of an 8-bit RGB picture to stay within 11 bits (+-1024); a picture that does
+    not pays with a second run of the whole transform.  No picture should: full-amplitude noise, saturated colour bars,
+    one- and two-pixel checkerboards and stripes in complementary colours, random saturated blocks -- the worst a forward
+    transform can make of 8-bit samples -- all decode on the packed kernels at the first attempt, losslessly."""
+    W, H = 1024, 512
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:H, 0:W]
+    pats = {
+        "noise": [rng.integers(0, 256, (H, W)).astype(np.int32) for _ in range(3)],
+        "bars": [(((xx // 128) >> k) & 1).astype(np.int32) * 255 for k in range(3)],
+        "checker": [(((xx + yy) & 1) * 255).astype(np.int32), (((xx + yy + 1) & 1) * 255).astype(np.int32), ((xx & 1) * 255).astype(np.int32)],
+        "stripes": [(((xx >> 1) & 1) * 255).astype(np.int32), ((((xx >> 1) + 1) & 1) * 255).astype(np.int32), (((xx >> 1) & 1) * 255).astype(np.int32)],
+        "blocks8": [np.kron(rng.integers(0, 2, (H // 8, W // 8)), np.ones((8, 8), int)).astype(np.int32) * 255 for _ in range(3)],
+        "blocks32": [np.kron(rng.integers(0, 2, (H // 32, W // 32)), np.ones((32, 32), int)).astype(np.int32) * 255 for _ in range(3)],
+    }
+    for name, img in pats.items():
+        data = vecgen.encode(img, mct=1, nlevels=5)
+        job = dec.job().parse_batch([data]).upload().run().wait()
+        assert job.coef16() and job.ll16() == 1 and job.idwt_packed() >= 10, (name, job.ll16(), job.idwt_packed())
+        assert np.array_equal(job.download_frame(0)[1][0].reshape(H, W, 3), np.stack(img, -1)), name
+        job.free()
+
+
 def test_ll16_overflow_runs_the_transform_again(dec, orc):
     """Nothing bounds the LL bands of crafted or corrupt coefficient data, so the level kernels flag a sample that does
     not fit and the job repeats the IDWT with int32 LL bands before it hands out frames.  A stream produced by a forward
