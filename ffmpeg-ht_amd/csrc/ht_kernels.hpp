@@ -1710,6 +1710,189 @@ __device__ __forceinline__ uint32_t ht_unstuff_forward7(const uint8_t *__restric
 }
 
 
+/* ---- the same un-stuffing with SEVERAL blocks per wave (k_ht_unstuff_g<LPB>: LPB lanes per block, 64 / LPB blocks) ----
+ * A wave per block spends its fixed costs -- set-up, zeroing and copying loops, a prefix sum and three LDS ORs per pass of
+ * 512 bytes -- on a VLC stream of a few hundred bytes (64 x 64 blocks) or a few dozen (32 x 32) that fills a fraction of
+ * one pass.  Here 16 (or 32) lanes take a block: a pass covers 128 (256) contiguous bytes of each of four (two) blocks, the
+ * prefix sum stops at the group (the first four, five, of the six DPP steps), the carries from one pass to the next and
+ * the group's bit total travel by ds_bpermute from the group's last lane.  Accesses stay contiguous per group (a lane per
+ * block does not pay: DESIGN.md section 3.1).  Blocks are sorted by size, so the groups of a wave end together. */
+template <int LPB>
+__device__ __forceinline__ uint32_t grp_incl_scan_u32(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    if (LPB >= 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    if (LPB >= 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
+template <int LPB>
+__device__ __forceinline__ uint32_t grp_last(uint32_t v, int lane)      /* the value the last lane of this lane's group holds */
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((lane | (LPB - 1)) << 2, (int)v);
+}
+template <bool OR_SEM, int LPB>
+__device__ __forceinline__ void ht_squeeze_place_g(uint32_t lo, uint32_t hi, uint32_t fl, uint32_t fh, int nv,
+                                                   uint32_t *out, int lane, uint32_t &base)
+{
+    const uint32_t tot = 8u * (uint32_t)nv - (uint32_t)__builtin_popcount(fl) - (uint32_t)__builtin_popcount(fh);
+    while (__ballot(fh != 0) != 0) {
+        if (fh) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(fh), bit = 1u << k, m = bit - 1u;
+            uint32_t nh = (hi & m) | ((hi >> 1) & ~m);
+            if (OR_SEM) nh |= hi & bit;
+            hi = nh;
+            fh &= m;
+        }
+    }
+    while (__ballot(fl != 0) != 0) {
+        if (fl) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(fl), bit = 1u << k, m = bit - 1u;
+            uint32_t nl = (lo & m) | (__builtin_amdgcn_alignbit(hi, lo, 1) & ~m);
+            if (OR_SEM) nl |= lo & bit;
+            lo = nl;
+            hi >>= 1;
+            fl &= m;
+        }
+    }
+    const uint32_t incl = grp_incl_scan_u32<LPB>(tot);
+    const uint32_t off = base + incl - tot;
+    if (nv > 0) {
+        const uint32_t sh = off & 31;
+        const uint64_t t = (uint64_t)lo << sh, u = (uint64_t)hi << sh;
+        uint32_t *o = out + (off >> 5);
+        atomicOr(o, (uint32_t)t);
+        atomicOr(o + 1, (uint32_t)(t >> 32) | (uint32_t)u);
+        if (sh + tot + (OR_SEM ? 1u : 0u) > 64) atomicOr(o + 2, (uint32_t)(u >> 32));
+    }
+    base += grp_last<LPB>(incl, lane);
+}
+__device__ __forceinline__ uint32_t ht_first_bytes(uint32_t v, int n) { return n >= 4 ? v : (n > 0 ? v & (0xFFFFFFFFu >> (32 - 8 * n)) : 0u); }
+/* eight bytes of a backward stream per lane: `dq` = the memory bytes top[-k-7 .. -k] of the lane's block, k = k0 + 8 gl
+ * (gl = lane within the group), `n` = the stream's length (0: the group has nothing to do), `carry` = "the byte before this
+ * pass was > 0x8F" at bit 7, per group */
+template <int LPB>
+__device__ __forceinline__ void ht_unstuff_backward_step8_g(uint2 dq, uint32_t k0, uint32_t n, uint32_t first_or,
+                                                            uint32_t *out, int lane, uint32_t &base, uint32_t &carry)
+{
+    const int gl = lane & (LPB - 1);
+    const uint32_t k = k0 + 8 * gl;
+    const int nv = min(max((int)n - (int)k, 0), 8);
+    uint32_t lo = __builtin_bswap32(dq.y), hi = __builtin_bswap32(dq.x);
+    if (k == 0) lo |= first_or;
+    lo = ht_first_bytes(lo, nv); hi = ht_first_bytes(hi, nv - 4);
+    const uint32_t ll = lo & 0x7F7F7F7Fu, lh = hi & 0x7F7F7F7Fu;
+    const uint32_t Al = (ll + 0x70707070u) & lo & 0x80808080u, Ah = (lh + 0x70707070u) & hi & 0x80808080u;
+    const uint32_t Bl = (ll + 0x01010101u) & 0x80808080u, Bh = (lh + 0x01010101u) & 0x80808080u;
+    uint32_t prevA = ht_dpp_left(Ah >> 24);
+    if (gl == 0) prevA = carry;
+    carry = grp_last<LPB>(Ah >> 24, lane);
+    const uint32_t fl = ht_first_bytes(Bl & ((Al << 8) | prevA), nv), fh = ht_first_bytes(Bh & __builtin_amdgcn_alignbyte(Ah, Al, 3), nv - 4);
+    ht_squeeze_place_g<false, LPB>(lo, hi, fl, fh, nv, out, lane, base);
+}
+/* ... of a forward stream whose bytes behind an 0xFF lose their top bit (SigProp): dq = bytes src[i .. i + 8), i = p0 + 8 gl */
+template <int LPB>
+__device__ __forceinline__ void ht_unstuff_fwd7_step8_g(uint2 dq, uint32_t p0, uint32_t n, uint32_t *out, int lane,
+                                                        uint32_t &base, uint32_t &carry)
+{
+    const int gl = lane & (LPB - 1);
+    const int nv = min(max((int)n - (int)(p0 + 8 * gl), 0), 8);
+    const uint32_t lo = ht_first_bytes(dq.x, nv), hi = ht_first_bytes(dq.y, nv - 4);
+    uint32_t prev = ht_dpp_left(hi >> 24);
+    if (gl == 0) prev = carry;
+    carry = grp_last<LPB>(hi >> 24, lane);
+    const uint32_t Pl = (lo << 8) | prev, Ph = __builtin_amdgcn_alignbyte(hi, lo, 3);
+    const uint32_t fl = ht_first_bytes(((Pl & 0x7F7F7F7Fu) + 0x01010101u) & Pl & 0x80808080u, nv);
+    const uint32_t fh = ht_first_bytes(((Ph & 0x7F7F7F7Fu) + 0x01010101u) & Ph & 0x80808080u, nv - 4);
+    ht_squeeze_place_g<false, LPB>(lo, hi, fl, fh, nv, out, lane, base);
+}
+
+template <int LPB>
+__global__ void __launch_bounds__(64)
+k_ht_unstuff_g(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
+               uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u, uint32_t lds_words)
+{
+    extern __shared__ __align__(16) uint32_t sw[];
+    constexpr int G = 64 / LPB;
+    const int lane = threadIdx.x, gl = lane & (LPB - 1);
+    const int bi = (int)blockIdx.x * G + lane / LPB;
+    J2kBlock b;
+    memset(&b, 0, sizeof(b));
+    if (bi < nblocks) b = blocks[bi];
+    const uint8_t *D = bytes + b.data_off;
+    const uint32_t Lcup = b.lcup;
+    /* (the blocks k_ht_unstuff leaves alone; nothing returns early: the wave's groups go through the barriers together) */
+    bool ok = bi < nblocks && b.npasses != 0 && Lcup >= 2;
+    uint2 pv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const long long o = (long long)b.data_off + Lcup - 9 - (8 * LPB * j + 8 * gl);
+        pv[j] = make_uint2(0u, 0u);
+        if (ok && o >= 0) __builtin_memcpy(&pv[j], bytes + o, 8);
+    }
+    uint32_t Scup = 0;
+    if (ok) Scup = ((uint32_t)D[Lcup - 1] << 4) + (D[Lcup - 2] & 0x0F);
+    ok = ok && !(Scup < 2 || Scup > Lcup || Scup > 4079);
+    const uint32_t nsw = ht_nsw(Scup);
+    ok = ok && 2 * nsw <= lds_words;
+    uint32_t *vlO = vlc_u + (b.data_off >> 2), *meO = mel_u + (b.data_off >> 2);
+    uint32_t *sv = sw + (size_t)(lane / LPB) * lds_words;
+
+    if (ok) for (uint32_t i = gl; i < nsw; i += LPB) sv[i] = 0;
+    __syncthreads();
+    {
+        const uint8_t *top = D + Lcup - 2;
+        const uint32_t n = ok ? Scup - 1 : 0u;
+        uint32_t base = 0, carry = 0x80;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (__ballot((uint32_t)(8 * LPB * j) < n) != 0) ht_unstuff_backward_step8_g<LPB>(pv[j], 8 * LPB * j, n, 0x0F, sv, lane, base, carry);
+        for (uint32_t k0 = 16 * LPB; __ballot(k0 < n) != 0; k0 += 8 * LPB) {
+            const uint32_t k = k0 + 8 * gl;
+            uint2 dq = make_uint2(0u, 0u);
+            if (k < n) __builtin_memcpy(&dq, top - k - 7, 8);
+            ht_unstuff_backward_step8_g<LPB>(dq, k0, n, 0x0F, sv, lane, base, carry);
+        }
+    }
+    __syncthreads();
+    if (ok) for (uint32_t i = gl; i < nsw; i += LPB) vlO[i] = sv[i];
+
+    const int rem = b.npasses % 3, plhd = rem ? b.npasses - rem : b.npasses - 3;
+    const uint32_t Lref = b.lref, nsp = ht_nsp(Lref);
+    const bool ref = ok && b.npasses - plhd > 1 && Lref > 0 && 2 * nsp <= lds_words;
+    if (__ballot(ref) == 0) return;                      /* (the whole wave) */
+    uint32_t *ss = sv, *sr = sv + nsp;
+    __syncthreads();
+    if (ref) for (uint32_t i = gl; i < 2 * nsp; i += LPB) sv[i] = 0;
+    __syncthreads();
+    {
+        const uint32_t n = ref ? Lref : 0u;
+        uint32_t base = 0, carry = 0;
+        for (uint32_t p0 = 0; __ballot(p0 < n) != 0; p0 += 8 * LPB) {
+            const uint32_t i = p0 + 8 * gl;
+            uint2 dq = make_uint2(0u, 0u);
+            if (i < n) __builtin_memcpy(&dq, D + Lcup + i, 8);
+            ht_unstuff_fwd7_step8_g<LPB>(dq, p0, n, ss, lane, base, carry);
+        }
+        base = 0; carry = 0x80;
+        const uint8_t *top = D + Lcup + Lref - 1;
+        for (uint32_t k0 = 0; __ballot(k0 < n) != 0; k0 += 8 * LPB) {
+            const uint32_t k = k0 + 8 * gl;
+            uint2 dq = make_uint2(0u, 0u);
+            if (k < n) __builtin_memcpy(&dq, top - k - 7, 8);
+            ht_unstuff_backward_step8_g<LPB>(dq, k0, n, 0, sr, lane, base, carry);
+        }
+    }
+    __syncthreads();
+    if (ref) for (uint32_t i = gl; i < nsp; i += LPB) {
+        vlO[nsw + i] = ss[i];
+        meO[nsw + i] = sr[i];
+    }
+}
+
 __global__ void __launch_bounds__(64)
 k_ht_unstuff(const J2kBlock *__restrict__ blocks, int nblocks, const uint8_t *__restrict__ bytes,
              uint32_t *__restrict__ vlc_u, uint32_t *__restrict__ mel_u, uint32_t lds_words)

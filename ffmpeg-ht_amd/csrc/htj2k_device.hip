@@ -1753,11 +1753,29 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
                 const uint32_t us_lds = us_words * 4;
-                if (us_lds > 48 * 1024)
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
-                hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
-                                   (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                   (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                /* blocks per wave of the un-stuffing kernel: four (16 lanes each) where no block is wider than 32 columns, else
+                 * two -- per 128 frames of C2 (64 x 64 blocks) 404 us with one, 378 with two, 456 with four (more passes, each
+                 * with its fixed cost); per 96 frames of C3 (32 x 32) 820 / 529 / 451 */
+                const int us_g = getenv("HTJ2K_UNSTUFF_G") ? atoi(getenv("HTJ2K_UNSTUFF_G")) : (j->max_qw <= 16 ? 4 : 2);
+                if (us_g == 4 && 4 * us_lds <= 64 * 1024) {
+                    if (4 * us_lds > 48 * 1024)
+                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * us_lds)));
+                    hipLaunchKernelGGL(k_ht_unstuff_g<16>, dim3((nblocks + 3) / 4), dim3(64), 4 * us_lds, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                } else if (us_g >= 2 && 2 * us_lds <= 64 * 1024) {
+                    if (2 * us_lds > 48 * 1024)
+                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * us_lds)));
+                    hipLaunchKernelGGL(k_ht_unstuff_g<32>, dim3((nblocks + 1) / 2), dim3(64), 2 * us_lds, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                } else {
+                    if (us_lds > 48 * 1024)
+                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
+                    hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
+                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
+                }
                 const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
                 if (vlc_narrow)
                     hipLaunchKernelGGL(k_ht_vlc2, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), HT_VLC2_LDS, j->stream,

@@ -276,6 +276,8 @@ void *htj2k_job_device_plane(htj2k_job *job, int plane, int *linesize);
  *   HTJ2K_LL16=0|1, HTJ2K_FUSE=0|1, HTJ2K_PK=0|1   "ll16", "fuse_pack", "idwt_pk"
  *   HTJ2K_MULTI_LDS=bytes            (per upload) most LDS a wave of k_ht_decode_multi may take for its blocks' MagSgn bits
  *                                    (default 12288): above it the job decodes one block per wave
+ *   HTJ2K_UNSTUFF_G=1|2|4            (per launch) codeblocks per wavefront in the un-stuffing kernel (default 4 for jobs without blocks wider
+ *                                    than 32 columns, else 2)
  *   HTJ2K_STRIP=rows                 (per launch) rows per wave of the streaming IDWT kernels (default 8 or 16 by launch size)
  *   HTJ2K_TW16 / HTJ2K_TW32 / HTJ2K_TWF=columns   (per launch) output columns per wave of the streaming IDWT for 16-bit LL
  *                                    bands / 32-bit LL bands / the fused final level (64 .. 244; default 224 or 244 by row length)
