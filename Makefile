@@ -14,13 +14,16 @@ all: lib oracle vecgen
 lib: $(PKG)/libhtj2k_amd.so
 oracle: oracle/libj2k_oracle.so
 vecgen: tools/vecgen/libhtj2k_vecgen.so
-ubench: tools/ubench/membw tools/ubench/occupancy
+ubench: tools/ubench/membw tools/ubench/occupancy tools/ubench/valu_rate
 examples: examples/htj2k_decode
 
 examples/htj2k_decode: examples/htj2k_decode.c include/htj2k_amd.h $(PKG)/libhtj2k_amd.so
 	$(CC) -O2 -Wall -std=gnu11 -Iinclude -o $@ $< -L$(PKG) -lhtj2k_amd -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 tools/ubench/membw: tools/ubench/membw.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
+
+tools/ubench/valu_rate: tools/ubench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
 tools/ubench/occupancy: tools/ubench/occupancy.hip $(wildcard $(CSRC)/*.hpp)
