@@ -180,7 +180,8 @@ struct DwtFusedArgs {
  * then runs the transform again with 32-bit LL bands (htj2k_device.hip, job_settle). */
 /* PK (FAST, 16-bit sub-bands and LL band; a plain level that stores a 16-bit LL band, or the fused final level with 8-bit
  * output of 8-bit components, OUTK 0 or 2): the whole step on pairs of 16-bit samples, see stream_hlift_pk */
-template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false>
+/* LLG: the 16-bit LL band is in global memory (everywhere but in k_idwt_stream_ll16_x3, whose LL inputs may be LDS windows) */
+template <int TYPE, int NC, bool FUSED, bool FAST, bool C16 = false, bool LL16 = false, int OUTK = 0, bool PK = false, bool LLG = FUSED>
 __device__ __forceinline__ void
 idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_base, const uint32_t *__restrict__ band_base,
                  uint32_t *__restrict__ out_base, const PackTile *__restrict__ T, int comp0, int th, int tw, int bx, int by,
@@ -272,7 +273,7 @@ idwt_stream_impl(const DwtTileArgs (&A)[NC], const uint32_t *__restrict__ ll_bas
                 Lr[c][1] = *(g_cu32 *)(brow0 + cb1);
                 Hr[c][0] = *(g_cu32 *)(brow1 + cb0);
                 Hr[c][1] = *(g_cu32 *)(brow1 + cb1);
-                if (LL16 && FUSED) {                           /* (a final level's LL band is in global memory) */
+                if (LL16 && LLG) {
                     g_cchar *lrow = sgpr_ptr((const uint16_t *)ll_base + A[c].ll_off + (size_t)(iy[0] - ll_row0) * A[c].ll_stride);
                     Lr[c][0] = *(g_cu32 *)(lrow + cb0);
                 } else if (LL16) {                             /* k_idwt_stream_ll16_x3: global memory or an LDS window */
@@ -800,7 +801,7 @@ k_idwt_stream_ll16(const DwtTileArgs *__restrict__ args, const uint32_t *__restr
     int bx, by, bz;
     if (!stream_strip(G, bx, by, bz)) return;
     const DwtTileArgs A[1] = { args[bz] };
-    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16, PK>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
+    idwt_stream_impl<J2K_DWT53, 1, false, true, true, true, 16, PK, true>(A, ll_base, band_base, out_base, nullptr, 0, th, G.tw, bx, by, ovf, ovf_bits);
 }
 
 /* ================================================================== three levels in one launch
