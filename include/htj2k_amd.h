@@ -146,9 +146,10 @@ int  htj2k_job_parse_batch(htj2k_ctx *ctx, const uint8_t *const *pkts, const int
 int  htj2k_job_parse_batch_ex(htj2k_ctx *ctx, const uint8_t *const *pkts, const int *pkt_sizes, int nframes,
                               const uint8_t *pinned, htj2k_job **job);
 int  htj2k_job_num_frames(const htj2k_job *job);
-/* host cost of the last htj2k_job_parse(_batch), per frame and per thread that worked on it: `ms_parse` the marker +
- * Tier-2 parse (no code-block byte is read with "device_gather", the default), `ms_stage` the copy of the packet
- * into pinned memory that the H2D transfer then starts from */
+/* host cost of the last htj2k_job_parse(_batch), averaged over its frames (each frame is timed on the thread that worked
+ * on it): `ms_parse` the marker + Tier-2 parse (no code-block byte is read with "device_gather", the default), `ms_stage`
+ * the copy of the packet into pinned memory that the H2D transfer starts from (for a single large packet, whose copy runs
+ * on helper threads under the parse: the part of it the parse did not cover) */
 int  htj2k_job_host_ms(const htj2k_job *job, float *ms_parse, float *ms_stage);
 int  htj2k_job_frame_info(const htj2k_job *job, int frame, htj2k_info *info);
 int  htj2k_job_download_frame(htj2k_ctx *ctx, htj2k_job *job, int frame, htj2k_frame *out);
