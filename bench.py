@@ -153,7 +153,10 @@ def bind_near_gpu(device_index, sysfs="/sys"):
         near = set()
     if len(near) < 4 or near == have:                     # nothing to gain, or a cgroup that put us elsewhere
         return {"numa_node": node, "bound": False, "cpus": len(have)}
-    os.sched_setaffinity(0, near)
+    try:
+        os.sched_setaffinity(0, near)
+    except OSError as e:                                  # a container that does not allow it: run unbound, say so
+        return {"numa_node": node, "bound": False, "cpus": len(have), "error": str(e)}
     return {"numa_node": node, "bound": True, "cpus": len(near)}
 
 
