@@ -7,13 +7,14 @@
  * (jpeg2000dec.c:2279-2287).  How it computes it is not the reference's byte-at-a-time
  * bit buffers.  The work of a block splits by its dependence structure:
  *
- *   un-stuffing (64 lanes per block)   k_ht_unstuff (VLC, SigProp, MagRef bytes: four bytes per lane) and the
- *                       head of the MagSgn kernels (eight bytes per lane): per-byte bit counts
- *                       (7 after a 0xFF, jpeg2000htdec.c:207-221; 7 for a 0x7F-low byte below a
- *                       >0x8F byte for the backward streams, :145-201), wave prefix sum -> bit
- *                       offset of the lane's chunk, ds_or into 32-bit words.
+ *   un-stuffing (16, 32 or 64 lanes per block)   k_ht_unstuff_g / k_ht_unstuff (VLC, SigProp, MagRef bytes) and the
+ *                       head of the MagSgn kernels, eight bytes per lane: the bytes that carry 7 bits are
+ *                       flagged by SWAR tests (after a 0xFF, jpeg2000htdec.c:207-221; a 0x7F-low byte below a
+ *                       >0x8F byte for the backward streams, :145-201), their spare bits squeezed out, then a
+ *                       prefix sum over the block's lanes -> bit offset of the lane's chunk, ds_or into
+ *                       32-bit words.
  *   serial chains (one LANE per block, 64 blocks per wave)
- *                       k_ht_vlc: MEL + CxtVLC + U-VLC of every quad (:632-973) -- "codeword
+ *                       k_ht_vlc2 (k_ht_vlc for blocks wider than 64 columns): MEL + CxtVLC + U-VLC of every quad (:632-973) -- "codeword
  *                       length -> next codeword position -> context" -- and k_ht_refine:
  *                       SigProp / MagRef (:1016-1185) -- "which sample takes the next bit depends
  *                       on the significance the previous bits made".  Neither parallelises
