@@ -83,7 +83,11 @@ struct DevBuf {
         /* test aid: fresh device memory is not zero in a long-lived process; HTJ2K_POISON=1 makes every new buffer
          * start as 0xA5 bytes so that a read of memory no kernel wrote shows up at once (tools/gpu_random_configs.py) */
         static const bool poison = getenv("HTJ2K_POISON") && atoi(getenv("HTJ2K_POISON"));
-        if (poison) (void)hipMemset(p, 0xA5, want);
+        if (poison) {                                     /* (the fill runs on the null stream and need not have happened when
+                                                            * hipMemset returns; the jobs' streams do not wait for that stream) */
+            (void)hipMemset(p, 0xA5, want);
+            (void)hipDeviceSynchronize();
+        }
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
