@@ -1570,6 +1570,25 @@ static void launch_tile_generic(const void *tab, int max_lh, int max_lv, int min
     }
 }
 
+/* the un-stuffing kernel with `g` codeblocks per wavefront (4, 2 or 1; fewer if the LDS of g blocks would not fit) */
+static hipError_t launch_unstuff(hipStream_t st, const J2kBlock *blocks, int nblocks, const uint8_t *bytes, uint32_t *vlcu, uint32_t *melu,
+                                 uint32_t us_words, int g)
+{
+    const size_t us_lds = (size_t)us_words * 4;
+    hipError_t e = hipSuccess;
+    if (g >= 4 && 4 * us_lds <= 64 * 1024) {
+        if (4 * us_lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_ht_unstuff_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * us_lds));
+        if (e == hipSuccess) hipLaunchKernelGGL(k_ht_unstuff_g<16>, dim3((nblocks + 3) / 4), dim3(64), 4 * us_lds, st, blocks, nblocks, bytes, vlcu, melu, us_words);
+    } else if (g >= 2 && 2 * us_lds <= 64 * 1024) {
+        if (2 * us_lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_ht_unstuff_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * us_lds));
+        if (e == hipSuccess) hipLaunchKernelGGL(k_ht_unstuff_g<32>, dim3((nblocks + 1) / 2), dim3(64), 2 * us_lds, st, blocks, nblocks, bytes, vlcu, melu, us_words);
+    } else {
+        if (us_lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, st, blocks, nblocks, bytes, vlcu, melu, us_words);
+    }
+    return e;
+}
+
 /* how many bits the 16-bit LL bands of a job must fit: 16, fewer where a packed final level needs it (pk16_eligibility) or a test says so */
 static int ll16_check_bits(const htj2k_ctx *c, const htj2k_job *j)
 {
@@ -1756,30 +1775,12 @@ extern "C" int htj2k_job_run_stages(htj2k_ctx *c, htj2k_job *j, int mask)
                 if ((int)j->lds_ext.total > 48 * 1024)
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)j->lds_ext.total));
                 const uint32_t us_words = 2 * std::max(j->lds.vlc_words, j->reflist.empty() ? 0u : ht_nsp(j->max_lref));
-                const uint32_t us_lds = us_words * 4;
                 /* blocks per wave of the un-stuffing kernel: four (16 lanes each) where no block is wider than 32 columns, else
                  * two -- per 128 frames of C2 (64 x 64 blocks) 404 us with one, 378 with two, 456 with four (more passes, each
                  * with its fixed cost); per 96 frames of C3 (32 x 32) 820 / 529 / 451 */
                 const int us_g = getenv("HTJ2K_UNSTUFF_G") ? atoi(getenv("HTJ2K_UNSTUFF_G")) : (j->max_qw <= 16 ? 4 : 2);
-                if (us_g == 4 && 4 * us_lds <= 64 * 1024) {
-                    if (4 * us_lds > 48 * 1024)
-                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * us_lds)));
-                    hipLaunchKernelGGL(k_ht_unstuff_g<16>, dim3((nblocks + 3) / 4), dim3(64), 4 * us_lds, j->stream,
-                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
-                } else if (us_g >= 2 && 2 * us_lds <= 64 * 1024) {
-                    if (2 * us_lds > 48 * 1024)
-                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * us_lds)));
-                    hipLaunchKernelGGL(k_ht_unstuff_g<32>, dim3((nblocks + 1) / 2), dim3(64), 2 * us_lds, j->stream,
-                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
-                } else {
-                    if (us_lds > 48 * 1024)
-                        HIP_TRY(c, hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds));
-                    hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, j->stream,
-                                       (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
-                                       (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words);
-                }
+                HIP_TRY(c, launch_unstuff(j->stream, (const J2kBlock *)j->d_blocks.p, nblocks, (const uint8_t *)j->d_bytes.p,
+                                          (uint32_t *)j->d_vlcu.p, (uint32_t *)j->d_melu.p, us_words, us_g));
                 const int vlc_wg = vlc_narrow ? 64 * HT_VLC_NARROW_WAVES : 64;
                 if (vlc_narrow)
                     hipLaunchKernelGGL(k_ht_vlc2, dim3((nblocks + vlc_wg - 1) / vlc_wg), dim3(vlc_wg), HT_VLC2_LDS, j->stream,
@@ -2497,11 +2498,9 @@ extern "C" int htj2k_ht_blocks(htj2k_ctx *c, const void *blocks_in, int nblocks,
             e = hipFuncSetAttribute((const void *)k_ht_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tmp.ext.total);
         if (e == hipSuccess) {
             const uint32_t us_words = 2 * std::max(tmp.lds.vlc_words, reflist.empty() ? 0u : ht_nsp(max_lref));
-            const uint32_t us_lds = us_words * 4;
-            if (us_lds > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)k_ht_unstuff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)us_lds);
-            hipLaunchKernelGGL(k_ht_unstuff, dim3(nblocks), dim3(64), us_lds, 0, (const J2kBlock *)db.p, nblocks,
-                               (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words);
+            /* (one block per wave unless a test asks otherwise: the unit entry keeps the plain kernels exercised) */
+            e = launch_unstuff(0, (const J2kBlock *)db.p, nblocks, (const uint8_t *)dby.p, (uint32_t *)du[0].p, (uint32_t *)du[1].p, us_words,
+                               getenv("HTJ2K_UNSTUFF_G") ? atoi(getenv("HTJ2K_UNSTUFF_G")) : 1);
             hipLaunchKernelGGL(k_ht_vlc, dim3((nblocks + 63) / 64), dim3(64), vlc_lds, 0, (const J2kBlock *)db.p, nblocks,
                                (const uint8_t *)dby.p, (const uint16_t *)c->d_tables, (ht_sym_t *)dq.p, (const uint32_t *)dqo.p,
                                tmp.lds.max_qw, (const uint32_t *)du[0].p, (const uint32_t *)du[1].p, (uint32_t *)dq.p + nq / 2 + 32);

@@ -306,10 +306,17 @@ def test_ht_block_decoder_unit(dec):
                 off += len(padded)
                 expect.append((soff, want))
                 soff += w * h
-    got, status = dec.ht_blocks(descs, pool, soff)
-    assert not status.any()
-    for (o, want) in expect:
-        assert np.array_equal(got[o:o + want.size].reshape(want.shape), want)
+    # ... through the un-stuffing kernel with one, two and four blocks per wavefront (the jobs' choice by block width;
+    # the unit entry runs one per wave unless told otherwise): streams of every length against the groups' pass sizes
+    try:
+        for g in ("1", "2", "4"):
+            os.environ["HTJ2K_UNSTUFF_G"] = g
+            got, status = dec.ht_blocks(descs, pool, soff)
+            assert not status.any(), g
+            for (o, want) in expect:
+                assert np.array_equal(got[o:o + want.size].reshape(want.shape), want), g
+    finally:
+        os.environ.pop("HTJ2K_UNSTUFF_G", None)
 
 
 def test_ht_block_errors_zero_the_block(dec):
