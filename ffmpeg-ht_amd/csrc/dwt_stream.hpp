@@ -24,6 +24,12 @@
  * C16 / LL16 below, decided in htj2k_device.hip) the sub-bands the block decoder wrote are read as
  * 16-bit pairs and widened in registers: 2.5 + 1 bytes per sample at the final level.
  *
+ * Round 3: a workgroup may hold up to eight such waves, which then take neighbouring strips and walk the same rows in step
+ * (stream_strip; what that does for the DRAM pages is worth 5-10 % of a launch); the 5/3 levels of 8-bit pictures run on
+ * pairs of 16-bit samples (PK: v_pk_* lifting, RCT and clip, half the instructions) where the host has proven that no
+ * intermediate leaves 16 bits; loads and stores take their row base from scalar registers (sgpr_ptr); and the first three
+ * levels of a plane are one launch with the LL bands in between held in LDS (k_idwt_stream_ll16_x3).
+ *
  * Boundaries: positions outside the line are fetched through the
  * whole-sample symmetric reflection (LineMap::idx), which is bit-identical to the reference's
  * sequential extend53/extend97 for lines of >= 2 samples; the lifting then runs on the extended
